@@ -1,0 +1,86 @@
+"""ctypes binding of ``libeeggan_hip.so`` (the C ABI declared in ``include/eeggan_hip.h``).
+
+The library is the only compute back end of this package: if it cannot be loaded the
+import of any compute entry point raises -- there is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeeggan_hip.so")
+
+_f = C.c_void_p      # device float*
+_i = C.c_int
+_fl = C.c_float
+_sz = C.c_size_t
+_st = C.c_void_p     # hipStream_t
+
+# name -> (restype, argtypes); every symbol include/eeggan_hip.h declares
+SIGNATURES = {
+    "eeggan_last_error": (C.c_char_p, []),
+    "eeggan_abi_version": (_i, []),
+    "eeggan_conv1d": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _i, _fl, _f, _f, _f, _fl, _st]),
+    "eeggan_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "eeggan_conv1d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _f, _fl, _f, _sz, _st]),
+    "eeggan_head_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),
+    "eeggan_head_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
+    "eeggan_head_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),
+    "eeggan_tail_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),
+    "eeggan_tail_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),
+    "eeggan_tail_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
+    "eeggan_lrelu_drop_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_pixelnorm_drop_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_pixelnorm_drop_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_tanh_bwd": (_i, [_f, _f, _f, _sz, _fl, _st]),
+    "eeggan_axpby": (_i, [_f, _fl, _f, _fl, _f, _sz, _st]),
+    "eeggan_mix_batch": (_i, [_f, _f, _f, _f, _i, _sz, _st]),
+    "eeggan_pow_base": (_i, [_f, _f, _sz, _fl, _st]),
+    "eeggan_resample": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "eeggan_mbstd_fwd": (_i, [_f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_wgan_gp_loss_fwd": (_i, [_f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
+    "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
+    "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),
+    "eeggan_mean_scale_bwd": (_i, [_f, _f, _i, _fl, _st]),
+    "eeggan_adam_step": (_i, [_f, C.c_void_p, _i, _fl, _fl, _fl, _fl, _i, _fl, _st]),
+    "eeggan_multi_copy": (_i, [_f, C.c_void_p, _i, _st]),
+}
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_MASK = 0, 1, 2, 3
+
+
+class EegganError(RuntimeError):
+    """An entry point of libeeggan_hip.so rejected its arguments or its launch failed."""
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every declared symbol; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). This package has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise EegganError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EegganError(lib.eeggan_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,62 @@
+"""The default configuration of the training step (reference defaults.yml:3-72, dataset.py:28-51,
+plugins.py:29-34) and helpers that build the default networks, optimizers and loss closures the
+way the reference's train.py:100-119,131-136,167-170 wires them."""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+
+PROGRESSION_SCALE_UP = [4, 2, 2, 3, 4, 5, 3]
+PROGRESSION_SCALE_DOWN = [1, 1, 1, 2, 3, 4, 2]
+INITIAL_KERNEL_SIZE = 32
+NUM_CHANNELS = 5
+LATENT_SIZE = 256
+RANDOM_SEED = 1373
+BASE_LR = 0.001
+ADAM = dict(betas=(0.0, 0.99), eps=1e-8, weight_decay=0)
+LOSS = dict(loss_type="wgan_gp", iwass_target=1.0, iwass_drift_epsilon=0.001, grad_lambda=10.0)
+MINIBATCH = {0: 256, 1: 256, 2: 128, 3: 128, 4: 48, 5: 32, 6: 32, 7: 32}
+
+
+def seq_len(depth: int) -> int:
+    t = INITIAL_KERNEL_SIZE
+    for i in range(depth):
+        t = t * PROGRESSION_SCALE_UP[i] // PROGRESSION_SCALE_DOWN[i]
+    return t
+
+
+def shared_model_kwargs():
+    return dict(initial_kernel_size=INITIAL_KERNEL_SIZE, num_rgb_channels=NUM_CHANNELS, fmap_base=1024, fmap_max=256,
+                fmap_min=64, kernel_size=3, self_attention_layers=[], progression_scale_up=PROGRESSION_SCALE_UP,
+                progression_scale_down=PROGRESSION_SCALE_DOWN, residual=False, separable=False, equalized=True,
+                init="kaiming_normal", act_alpha=0.2, num_classes=0, deep=False)
+
+
+GENERATOR_KWARGS = dict(spectral=False, latent_size=LATENT_SIZE, no_tanh=False, per_channel_noise=False,
+                        to_rgb_mode="pggan", split_z=False, dropout=0.2, act_norm="pixel", normalize_latents=True,
+                        z_to_bn=False, conv_only=False, shared_embedding_size=32, rgb_generation_mode="pggan")
+DISCRIMINATOR_KWARGS = dict(spectral=False, dropout=0.2, act_norm=None, group_size=4, temporal_groups_per_window=1,
+                            conv_only=False, input_to_all_layers=False)
+
+
+def build_models(seed: int = RANDOM_SEED, generator_cls=None, discriminator_cls=None):
+    """Generator then Discriminator, constructed right after seeding torch, on the CPU."""
+    if generator_cls is None:
+        from .network import Discriminator, Generator
+        generator_cls, discriminator_cls = Generator, Discriminator
+    torch.manual_seed(seed)
+    g = generator_cls(**shared_model_kwargs(), z_distribution="normal", **GENERATOR_KWARGS)
+    d = discriminator_cls(**shared_model_kwargs(), **DISCRIMINATOR_KWARGS)
+    return g, d
+
+
+def loss_closures():
+    from .losses import discriminator_loss, generator_loss
+    d_loss = partial(discriminator_loss, **LOSS)
+    g_loss = partial(generator_loss, random_multiply=False, loss_type=LOSS["loss_type"], feature_matching_lambda=0.0)
+    return d_loss, g_loss
+
+
+def stage_lr(depth: int, base_lr: float = BASE_LR, minibatch_default: int = 256) -> float:
+    return minibatch_default * base_lr / MINIBATCH.get(depth, minibatch_default)

@@ -1,0 +1,554 @@
+// Equalized-lr Conv1d (stride 1, same padding, K in {1,3}) as fp32 MFMA implicit GEMM
+// for gfx950: forward / input-gradient (one kernel, two weight views) and
+// weight-gradient (split over the batch*time axis, deterministic two-stage sum).
+//
+// Data layout: activations [B, C, T] (T fastest).  The flattened column space of a
+// layer is (sample, 32-wide time subtile); a workgroup owns NT consecutive subtiles.
+// In LDS every subtile carries its own left/right halo sample, so subtiles are
+// independent of each other and of sample boundaries (zero padding is a zero halo):
+//     row = [3 unused][halo t0-1][32 samples t0..t0+31][halo t0+32][3 unused]  = 40 floats
+// which keeps the 32 main samples 16-byte aligned for vector LDS stores.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain):
+//   forward/dgrad:  D[co][t]  += A[co][k] * B[k][t],  k = (ci, tap)
+//   wgrad:          D[co][ci] += A[co][k] * B[k][ci], k = (sample, t), one D per tap
+// With time on the MFMA column (= lane) axis every accumulator register is a run of
+// 32 consecutive time steps of one output channel: 128-byte coalesced stores.
+#include "common.h"
+
+namespace eeggan {
+namespace {
+
+constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment)
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* drop;
+    float* y;
+    const float* mask_y;
+    const float* mask_drop;
+    float mask_slope;
+    int B, Cin, Cout, T;
+    int ST;  // 32-wide subtiles per sample = ceil(T/32)
+    int NS;  // total subtiles = B*ST
+    int wsA, wsB, wsC, wOff;  // weight address = co*wsA + ci*wsB + tap*wsC + wOff
+    int transposed;
+    float in_scale;
+    int act;
+    float act_param;
+    const float* act_aux;
+    int vec;  // T % 4 == 0: 16-byte global loads are aligned
+};
+
+// ---------------------------------------------------------------------------------------
+// Global -> register -> LDS staging of ROWS channels x NT subtiles of an activation.
+template <int ROWS, int NT, int LD, bool HALO>
+struct XStage {
+    static constexpr int NV = ROWS * NT * 8;  // float4 items
+    static constexpr int VPT = (NV + 255) / 256;
+    static constexpr int NH = ROWS * NT * 2;  // halo items
+    static constexpr int HPT = (NH + 255) / 256;
+    static_assert(32 % NT == 0, "NT must divide 32");
+    f32x4 v[VPT];
+    float hv[HPT];
+
+    __device__ __forceinline__ void load(const float* __restrict__ src, const float* __restrict__ mask_y,
+                                         const float* __restrict__ mask_drop, float slope, int C, int T,
+                                         int ST, int NS, int sub0, int c0, bool vec) {
+        const int tid = threadIdx.x;
+        {
+            const int q = tid & 7;
+            const int n = (tid >> 3) % NT;
+            const int sub = sub0 + n;
+            const int b = sub / ST;
+            const int t = (sub - b * ST) * 32 + 4 * q;
+            const int row0 = (tid >> 3) / NT;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int row = row0 + i * (32 / NT);
+                const int c = c0 + row;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (row < ROWS && c < C && sub < NS && t < T) {
+                    const long long off = ((long long)b * C + c) * T + t;
+                    if (vec) {
+                        val = *reinterpret_cast<const f32x4*>(src + off);
+                        if (mask_y) {
+                            const f32x4 my = *reinterpret_cast<const f32x4*>(mask_y + off);
+                            const float md = mask_drop ? mask_drop[b * C + c] : 1.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] *= md * (my[e] > 0.f ? 1.f : slope);
+                        }
+                    } else {
+                        const float md = (mask_y && mask_drop) ? mask_drop[b * C + c] : 1.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (t + e < T) {
+                                float u = src[off + e];
+                                if (mask_y) u *= md * (mask_y[off + e] > 0.f ? 1.f : slope);
+                                val[e] = u;
+                            }
+                        }
+                    }
+                }
+                v[i] = val;
+            }
+        }
+        if (HALO) {
+            const int side = tid & 1;
+            const int n = (tid >> 1) % NT;
+            const int sub = sub0 + n;
+            const int b = sub / ST;
+            const int t = (sub - b * ST) * 32 + (side ? 32 : -1);
+            const int row0 = (tid >> 1) / NT;
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int row = row0 + i * (128 / NT);
+                const int c = c0 + row;
+                float u = 0.f;
+                if (row < ROWS && c < C && sub < NS && t >= 0 && t < T) {
+                    const long long off = ((long long)b * C + c) * T + t;
+                    u = src[off];
+                    if (mask_y) {
+                        const float md = mask_drop ? mask_drop[b * C + c] : 1.f;
+                        u *= md * (mask_y[off] > 0.f ? 1.f : slope);
+                    }
+                }
+                hv[i] = u;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds) const {
+        const int tid = threadIdx.x;
+        {
+            const int q = tid & 7;
+            const int n = (tid >> 3) % NT;
+            const int row0 = (tid >> 3) / NT;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int row = row0 + i * (32 / NT);
+                if (row < ROWS) *reinterpret_cast<f32x4*>(lds + row * LD + n * SUB + 4 + 4 * q) = v[i];
+            }
+        }
+        if (HALO) {
+            const int side = tid & 1;
+            const int n = (tid >> 1) % NT;
+            const int row0 = (tid >> 1) / NT;
+#pragma unroll
+            for (int i = 0; i < HPT; ++i) {
+                const int row = row0 + i * (128 / NT);
+                if (row < ROWS) lds[row * LD + n * SUB + (side ? 36 : 3)] = hv[i];
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Forward / input-gradient kernel.
+//   K   taps (1 or 3);  CT output channels per workgroup;  NT subtiles per workgroup;
+//   CK  input channels per K-chunk;  WM x WN wave grid over (channel tiles x subtiles).
+template <int K, int CT, int NT, int CK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
+    constexpr int XLD = NT * SUB;
+    constexpr int RM = CT / 32 / WM;
+    constexpr int RN = NT / WN;
+    constexpr int KH = CK / 2 * K;  // k-steps per chunk (each MFMA consumes 2 reduction indices)
+    constexpr int WE = CT * CK * K;  // weight elements per chunk
+    constexpr int WPT = (WE + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(KH % 4 == 0, "k-steps must group by 4 for b128 reads");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;             // [CT][WLD]
+    float* Xs = smem + CT * WLD;  // [CK][XLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int sub0 = blockIdx.x * NT;
+    const int co0 = blockIdx.y * CT;
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    XStage<CK, NT, XLD, (K > 1)> xs;
+    float wreg[WPT];
+
+    auto load_w = [&](int chunk) {
+        const int ci0 = chunk * CK;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + 256 * i;
+            int row, cl, j;
+            if (!a.transposed) {  // memory order: [co][ci][tap]
+                row = e / (CK * K);
+                const int rem = e - row * (CK * K);
+                cl = rem / K;
+                j = rem - cl * K;
+            } else {  // memory order of the forward weight: [ci][co][tap]
+                cl = e / (CT * K);
+                const int rem = e - cl * (CT * K);
+                row = rem / K;
+                j = K - 1 - (rem - row * K);
+            }
+            const int co = co0 + row, ci = ci0 + cl;
+            float val = 0.f;
+            if (e < WE && co < a.Cout && ci < a.Cin)
+                val = a.w[(long long)co * a.wsA + (long long)ci * a.wsB + j * a.wsC + a.wOff] * a.in_scale;
+            wreg[i] = val;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + 256 * i;
+            int row, cl, j;
+            if (!a.transposed) {
+                row = e / (CK * K);
+                const int rem = e - row * (CK * K);
+                cl = rem / K;
+                j = rem - cl * K;
+            } else {
+                cl = e / (CT * K);
+                const int rem = e - cl * (CT * K);
+                row = rem / K;
+                j = K - 1 - (rem - row * K);
+            }
+            if (e < WE) Ws[row * WLD + cl * K + j] = wreg[i];
+        }
+    };
+
+    const int nchunks = (a.Cin + CK - 1) / CK;
+    load_w(0);
+    xs.load(a.x, a.mask_y, a.mask_drop, a.mask_slope, a.Cin, a.T, a.ST, a.NS, sub0, 0, a.vec);
+    store_w();
+    xs.store(Xs);
+    __syncthreads();
+
+    const float* Ap = Ws + (wm * RM * 32 + l31) * WLD + h * KH;
+    const float* Bp = Xs + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) {
+            load_w(chunk + 1);
+            xs.load(a.x, a.mask_y, a.mask_drop, a.mask_slope, a.Cin, a.T, a.ST, a.NS, sub0, (chunk + 1) * CK,
+                    a.vec);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < KH / 4; ++s4) {
+            f32x4 av[RM];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const f32x4*>(Ap + i * 32 * WLD + 4 * s4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * s4 + u;
+                const int cl = s / K;
+                const int j = s - cl * K;
+                float bv[RN];
+#pragma unroll
+                for (int n = 0; n < RN; ++n) bv[n] = Bp[cl * XLD + n * SUB + j];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int n = 0; n < RN; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[n], acc[i][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_w();
+            xs.store(Xs);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: bias -> activation -> per-(sample, channel) multiplier -> store
+#pragma unroll
+    for (int n = 0; n < RN; ++n) {
+        const int sub = sub0 + wn * RN + n;
+        if (sub >= a.NS) continue;
+        const int b = sub / a.ST;
+        const int t = (sub - b * a.ST) * 32 + l31;
+        if (t >= a.T) continue;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (co < a.Cout) {
+                    float v = acc[i][n][r];
+                    const long long o = ((long long)b * a.Cout + co) * a.T + t;
+                    if (a.bias) v += a.bias[co];
+                    if (a.act == EEGGAN_ACT_LRELU)
+                        v = v > 0.f ? v : v * a.act_param;
+                    else if (a.act == EEGGAN_ACT_TANH)
+                        v = tanhf(v * a.act_param);
+                    else if (a.act == EEGGAN_ACT_MASK)
+                        v = a.act_aux[o] > 0.f ? v : v * a.act_param;
+                    if (a.drop) v *= a.drop[b * a.Cout + co];
+                    a.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int K, int CT, int NT, int CK, int WM, int WN>
+int launch_fwd(const ConvArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(CT * (CK * K + 4) + CK * NT * SUB) * sizeof(float);
+    dim3 grid((a.NS + NT - 1) / NT, (a.Cout + CT - 1) / CT);
+    hipLaunchKernelGGL((conv_fwd_kernel<K, CT, NT, CK, WM, WN>), grid, dim3(256), lds, st, a);
+    return check_launch("conv1d");
+}
+
+template <int K>
+int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
+    if (a.Cin <= 16) {
+        if (a.Cout <= 32) return launch_fwd<K, 32, 8, 16, 1, 4>(a, st);
+        if (a.Cout <= 64) return launch_fwd<K, 64, 4, 16, 1, 4>(a, st);
+        return launch_fwd<K, 128, 4, 16, 2, 2>(a, st);
+    }
+    if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4>(a, st);
+    if (a.Cout <= 64) return launch_fwd<K, 64, 4, 32, 1, 4>(a, st);
+    return launch_fwd<K, 128, 4, 16, 2, 2>(a, st);  // 37 KB of LDS: two workgroups per CU
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient.  A workgroup owns a 64(co) x 64(ci) x K region of gw and a contiguous
+// range of subtile pairs; wave w accumulates the 32x32xK tile (co half = w>>1, ci half = w&1).
+struct WgradArgs {
+    const float* x;
+    const float* gy;
+    const float* mask_y;
+    const float* mask_drop;
+    float mask_slope;
+    float* ws;    // [nsplit][Cout*Cin*K]
+    float* ws_b;  // [nsplit][Cout] or null
+    int B, Cin, Cout, T, ST, NS;
+    int nci;      // ci regions
+    int nsplit;
+    int iters;    // subtile pairs per split
+    int vec;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NTW = 2;
+    constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;            // [64][LD]
+    float* Xs = smem + 64 * LD;  // [64][LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const int wave = tid >> 6;
+    const int cot = wave >> 1, cit = wave & 1;
+    const int region = blockIdx.y;
+    const int co0 = (region / a.nci) * 64;
+    const int ci0 = (region % a.nci) * 64;
+    const int split = blockIdx.x;
+    const bool do_bias = a.ws_b != nullptr && ci0 == 0 && cit == 0;
+
+    f32x16 acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+
+    XStage<64, NTW, LD, false> gs;
+    XStage<64, NTW, LD, (K > 1)> xs;
+
+    const int it0 = split * a.iters;
+    const int total_pairs = (a.NS + NTW - 1) / NTW;
+    int it1 = it0 + a.iters;
+    if (it1 > total_pairs) it1 = total_pairs;
+
+    if (it0 < it1) {
+        gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, it0 * NTW, co0, a.vec);
+        xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, it0 * NTW, ci0, a.vec);
+    }
+    for (int it = it0; it < it1; ++it) {
+        gs.store(Gs);
+        xs.store(Xs);
+        __syncthreads();
+        if (it + 1 < it1) {
+            gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, (it + 1) * NTW, co0,
+                    a.vec);
+            xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, (it + 1) * NTW, ci0, a.vec);
+        }
+        const float* Gp = Gs + (cot * 32 + l31) * LD + 4 + 4 * h;
+        const float* Xp = Xs + (cit * 32 + l31) * LD + 4 + 4 * h;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(Gp + n * SUB + 8 * g);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(Xp + n * SUB + 8 * g);
+                float e[6];
+                e[1] = xv[0];
+                e[2] = xv[1];
+                e[3] = xv[2];
+                e[4] = xv[3];
+                if (K > 1) {
+                    e[0] = Xp[n * SUB + 8 * g - 1];
+                    e[5] = Xp[n * SUB + 8 * g + 4];
+                }
+                if (do_bias) bsum += (av[0] + av[1]) + (av[2] + av[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], e[q + j + 1 - PAD], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const long long E = (long long)a.Cout * a.Cin * K;
+    float* slab = a.ws + (long long)split * E;
+    const int ci = ci0 + cit * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout && ci < a.Cin) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) slab[((long long)co * a.Cin + ci) * K + j] = acc[j][r];
+        }
+    }
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int co = co0 + cot * 32 + l31;
+        if (h == 0 && co < a.Cout) a.ws_b[(long long)split * a.Cout + co] = bsum;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, long long E,
+                                                           float scale, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * E + i];
+    out[i] = s * scale;
+}
+
+struct WgradPlan {
+    int nco, nci, regions, nsplit, iters;
+    size_t slab_elems, bytes;
+};
+
+WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K) {
+    WgradPlan p;
+    p.nco = (Cout + 63) / 64;
+    p.nci = (Cin + 63) / 64;
+    p.regions = p.nco * p.nci;
+    const int ST = (T + 31) / 32;
+    const int pairs = (B * ST + 1) / 2;
+    int want = (512 + p.regions - 1) / p.regions;  // ~2 workgroups per CU over the whole grid
+    if (want > pairs) want = pairs;
+    if (want < 1) want = 1;
+    p.iters = (pairs + want - 1) / want;
+    p.nsplit = (pairs + p.iters - 1) / p.iters;
+    p.slab_elems = (size_t)Cout * Cin * K;
+    p.bytes = ((size_t)p.nsplit * (p.slab_elems + Cout) * sizeof(float) + 255) & ~(size_t)255;
+    return p;
+}
+
+int check_common(int B, int Cin, int Cout, int T, int K) {
+    EEGGAN_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && T > 0, "conv1d: non-positive dimension B=%d Cin=%d Cout=%d T=%d", B,
+                   Cin, Cout, T);
+    EEGGAN_REQUIRE(K == 1 || K == 3, "conv1d: kernel size %d not supported (1 or 3)", K);
+    EEGGAN_REQUIRE((long long)B * ((T + 31) / 32) < (1ll << 30), "conv1d: B*T too large");
+    EEGGAN_REQUIRE((long long)B * (Cin > Cout ? Cin : Cout) * T < (1ll << 40), "conv1d: tensor too large");
+    return 0;
+}
+
+}  // namespace
+}  // namespace eeggan
+
+using namespace eeggan;
+
+extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, const float* drop, float* y, int B,
+                             int Cin, int Cout, int T, int K, float in_scale, int transposed, int act,
+                             float act_param, const float* act_aux, const float* mask_y, const float* mask_drop,
+                             float mask_slope, void* stream) {
+    if (check_common(B, Cin, Cout, T, K)) return 1;
+    EEGGAN_REQUIRE(x && w && y, "conv1d: null x/w/y pointer");
+    EEGGAN_REQUIRE(act >= 0 && act <= 3, "conv1d: unknown activation code %d", act);
+    EEGGAN_REQUIRE(act != EEGGAN_ACT_MASK || act_aux, "conv1d: EEGGAN_ACT_MASK needs act_aux");
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.drop = drop; a.y = y;
+    a.mask_y = mask_y; a.mask_drop = mask_y ? mask_drop : nullptr; a.mask_slope = mask_slope;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
+    a.ST = (T + 31) / 32;
+    a.NS = B * a.ST;
+    a.transposed = transposed ? 1 : 0;
+    if (!transposed) {
+        a.wsA = Cin * K; a.wsB = K; a.wsC = 1; a.wOff = 0;
+    } else {  // forward weight is [Cin_arg][Cout_arg][K]; taps flipped
+        a.wsA = K; a.wsB = Cout * K; a.wsC = -1; a.wOff = K - 1;
+    }
+    a.in_scale = in_scale; a.act = act; a.act_param = act_param; a.act_aux = act_aux;
+    a.vec = (T % 4 == 0) ? 1 : 0;
+    hipStream_t st = as_stream(stream);
+    return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
+}
+
+extern "C" size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T, int K) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || (K != 1 && K != 3)) return 0;
+    return plan_wgrad(B, Cin, Cout, T, K).bytes;
+}
+
+extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
+                                   int T, int K, float in_scale, const float* mask_y, const float* mask_drop,
+                                   float mask_slope, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_common(B, Cin, Cout, T, K)) return 1;
+    EEGGAN_REQUIRE(x && gy && gw, "conv1d_wgrad: null x/gy/gw pointer");
+    const WgradPlan p = plan_wgrad(B, Cin, Cout, T, K);
+    EEGGAN_REQUIRE(workspace && workspace_bytes >= p.bytes, "conv1d_wgrad: workspace too small (%zu < %zu bytes)",
+                   workspace_bytes, p.bytes);
+    WgradArgs a;
+    a.x = x; a.gy = gy; a.mask_y = mask_y; a.mask_drop = mask_y ? mask_drop : nullptr; a.mask_slope = mask_slope;
+    a.ws = static_cast<float*>(workspace);
+    a.ws_b = gb ? a.ws + (size_t)p.nsplit * p.slab_elems : nullptr;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
+    a.ST = (T + 31) / 32;
+    a.NS = B * a.ST;
+    a.nci = p.nci; a.nsplit = p.nsplit; a.iters = p.iters;
+    a.vec = (T % 4 == 0) ? 1 : 0;
+    hipStream_t st = as_stream(stream);
+    constexpr size_t lds = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
+    dim3 grid(p.nsplit, p.regions);
+    if (K == 3)
+        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
+    if (check_launch("conv1d_wgrad")) return 1;
+    const long long E = (long long)p.slab_elems;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a.ws, p.nsplit, E,
+                       in_scale, gw);
+    if (check_launch("conv1d_wgrad reduce")) return 1;
+    if (gb) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, a.ws_b,
+                           p.nsplit, (long long)Cout, 1.0f, gb);
+        if (check_launch("conv1d_wgrad bias reduce")) return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,317 @@
+// Bandwidth-bound elementwise / per-column normalisation kernels (fp32, [B, C, T]).
+// All of them read each logical input once and write each output once; rows are walked
+// with 16-byte accesses whenever T (or n) is a multiple of 4.
+#include "common.h"
+
+namespace eeggan {
+namespace {
+
+constexpr int MAX_BLOCKS = 256 * 8;
+
+inline unsigned blocks_for(size_t items) {
+    size_t b = (items + 255) / 256;
+    if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ---- leaky-relu + drop backward ------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                             const float* __restrict__ drop, float* __restrict__ out,
+                                                             size_t n, int T, float slope) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t items = n / W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const size_t e = i * W;
+        const float r = drop ? drop[e / T] : 1.f;
+        if (VEC) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = gv[k] * r * (yv[k] > 0.f ? 1.f : slope);
+            *reinterpret_cast<f32x4*>(out + e) = o;
+        } else {
+            out[e] = g[e] * r * (y[e] > 0.f ? 1.f : slope);
+        }
+    }
+}
+
+// ---- pixel norm (+drop) ---------------------------------------------------------------------
+// Workgroup = 4 channel groups x 64 column units; a unit is 4 (VEC) or 1 time steps of one sample.
+template <bool VEC>
+__global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ h, const float* __restrict__ drop,
+                                                            float* __restrict__ y, float* __restrict__ d, int B, int C,
+                                                            int T, float eps) {
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float red[4][64][W];
+    const int cg = threadIdx.x >> 6, ul = threadIdx.x & 63;
+    const int upr = T / W;  // units per row
+    const long long unit = (long long)blockIdx.x * 64 + ul;
+    const bool ok = unit < (long long)B * upr;
+    const int b = ok ? (int)(unit / upr) : 0;
+    const int t = ok ? (int)(unit - (long long)b * upr) * W : 0;
+    float s[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) s[k] = 0.f;
+    if (ok) {
+        for (int c = cg; c < C; c += 4) {
+            const long long off = ((long long)b * C + c) * T + t;
+            if (VEC) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
+#pragma unroll
+                for (int k = 0; k < W; ++k) s[k] += v[k] * v[k];
+            } else {
+                const float v = h[off];
+                s[0] += v * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[cg][ul][k] = s[k];
+    __syncthreads();
+    if (!ok) return;
+    float dv[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const float tot = (red[0][ul][k] + red[1][ul][k]) + (red[2][ul][k] + red[3][ul][k]);
+        dv[k] = rsqrtf(tot / (float)C + eps);
+    }
+    if (cg == 0) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) d[(long long)b * T + t + k] = dv[k];
+    }
+    for (int c = cg; c < C; c += 4) {
+        const long long off = ((long long)b * C + c) * T + t;
+        const float r = drop ? drop[b * C + c] : 1.f;
+        if (VEC) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < W; ++k) o[k] = v[k] * dv[k] * r;
+            *reinterpret_cast<f32x4*>(y + off) = o;
+        } else {
+            y[off] = h[off] * dv[0] * r;
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            const float* __restrict__ drop, const float* __restrict__ d,
+                                                            float* __restrict__ gc, int B, int C, int T, float slope) {
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float red[4][64][W];
+    const int cg = threadIdx.x >> 6, ul = threadIdx.x & 63;
+    const int upr = T / W;
+    const long long unit = (long long)blockIdx.x * 64 + ul;
+    const bool ok = unit < (long long)B * upr;
+    const int b = ok ? (int)(unit / upr) : 0;
+    const int t = ok ? (int)(unit - (long long)b * upr) * W : 0;
+    float s[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) s[k] = 0.f;
+    if (ok) {
+        for (int c = cg; c < C; c += 4) {
+            const long long off = ((long long)b * C + c) * T + t;
+            if (VEC) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+#pragma unroll
+                for (int k = 0; k < W; ++k) s[k] += a[k] * v[k];
+            } else {
+                s[0] += gy[off] * y[off];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) red[cg][ul][k] = s[k];
+    __syncthreads();
+    if (!ok) return;
+    float S[W], dv[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        S[k] = ((red[0][ul][k] + red[1][ul][k]) + (red[2][ul][k] + red[3][ul][k])) / (float)C;
+        dv[k] = d[(long long)b * T + t + k];
+    }
+    for (int c = cg; c < C; c += 4) {
+        const long long off = ((long long)b * C + c) * T + t;
+        const float r = drop ? drop[b * C + c] : 1.f;
+        const float ir = 1.f / r;
+        if (VEC) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                o[k] = dv[k] * (a[k] * r - v[k] * ir * S[k]) * (v[k] > 0.f ? 1.f : slope);
+            *reinterpret_cast<f32x4*>(gc + off) = o;
+        } else {
+            const float a = gy[off], v = y[off];
+            gc[off] = dv[0] * (a * r - v * ir * S[0]) * (v > 0.f ? 1.f : slope);
+        }
+    }
+}
+
+// ---- small flat kernels ------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                       float* __restrict__ gc, size_t n, float scale) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t items = n / W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        if (VEC) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(gy)[i];
+            const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = a[k] * scale * (1.f - v[k] * v[k]);
+            reinterpret_cast<f32x4*>(gc)[i] = o;
+        } else {
+            gc[i] = gy[i] * scale * (1.f - y[i] * y[i]);
+        }
+    }
+}
+
+template <bool VEC, bool HASB>
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, float ca, const float* __restrict__ b,
+                                                    float cb, float* __restrict__ out, size_t n) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t items = n / W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        if (VEC) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+            f32x4 o;
+            if (HASB) {
+                const f32x4 z = reinterpret_cast<const f32x4*>(b)[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = x[k] * ca + z[k] * cb;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = x[k] * ca;
+            }
+            reinterpret_cast<f32x4*>(out)[i] = o;
+        } else {
+            out[i] = HASB ? a[i] * ca + b[i] * cb : a[i] * ca;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_batch_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                        const float* __restrict__ mix, float* __restrict__ out,
+                                                        size_t n, size_t per) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float m = mix[i / per];
+        out[i] = m * real[i] + (1.f - m) * fake[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void pow_base_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                       size_t n, float log_base) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = expf(x[i] * log_base);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace eeggan
+
+using namespace eeggan;
+
+extern "C" int eeggan_lrelu_drop_bwd(const float* g, const float* y, const float* drop, float* out, int B, int C,
+                                     int T, float slope, void* stream) {
+    EEGGAN_REQUIRE(g && y && out, "lrelu_drop_bwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "lrelu_drop_bwd: non-positive dimension");
+    const size_t n = (size_t)B * C * T;
+    const bool vec = (T % 4 == 0) && aligned16(g) && aligned16(y) && aligned16(out);
+    if (vec)
+        hipLaunchKernelGGL(lrelu_drop_bwd_kernel<true>, dim3(blocks_for(n / 4)), dim3(256), 0, as_stream(stream), g, y,
+                           drop, out, n, T, slope);
+    else
+        hipLaunchKernelGGL(lrelu_drop_bwd_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), g, y,
+                           drop, out, n, T, slope);
+    return check_launch("lrelu_drop_bwd");
+}
+
+extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, float* y, float* d, int B, int C, int T,
+                                         float eps, void* stream) {
+    EEGGAN_REQUIRE(h && y && d, "pixelnorm_drop_fwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_fwd: non-positive dimension");
+    const bool vec = (T % 4 == 0) && aligned16(h) && aligned16(y) && aligned16(d);
+    const long long units = (long long)B * (vec ? T / 4 : T);
+    const unsigned grid = (unsigned)((units + 63) / 64);
+    if (vec)
+        hipLaunchKernelGGL(pixelnorm_fwd_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), h, drop, y, d, B, C,
+                           T, eps);
+    else
+        hipLaunchKernelGGL(pixelnorm_fwd_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), h, drop, y, d, B,
+                           C, T, eps);
+    return check_launch("pixelnorm_drop_fwd");
+}
+
+extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop, const float* d, float* gc,
+                                         int B, int C, int T, float slope, void* stream) {
+    EEGGAN_REQUIRE(gy && y && d && gc, "pixelnorm_drop_bwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_bwd: non-positive dimension");
+    const bool vec = (T % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
+    const long long units = (long long)B * (vec ? T / 4 : T);
+    const unsigned grid = (unsigned)((units + 63) / 64);
+    if (vec)
+        hipLaunchKernelGGL(pixelnorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), gy, y, drop, d, gc,
+                           B, C, T, slope);
+    else
+        hipLaunchKernelGGL(pixelnorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), gy, y, drop, d,
+                           gc, B, C, T, slope);
+    return check_launch("pixelnorm_drop_bwd");
+}
+
+extern "C" int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_t n, float scale, void* stream) {
+    EEGGAN_REQUIRE(gy && y && gc && n > 0, "tanh_bwd: null pointer or empty");
+    const bool vec = (n % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
+    if (vec)
+        hipLaunchKernelGGL(tanh_bwd_kernel<true>, dim3(blocks_for(n / 4)), dim3(256), 0, as_stream(stream), gy, y, gc,
+                           n, scale);
+    else
+        hipLaunchKernelGGL(tanh_bwd_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), gy, y, gc, n,
+                           scale);
+    return check_launch("tanh_bwd");
+}
+
+extern "C" int eeggan_axpby(const float* a, float ca, const float* b, float cb, float* out, size_t n, void* stream) {
+    EEGGAN_REQUIRE(a && out && n > 0, "axpby: null pointer or empty");
+    const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(out) && (!b || aligned16(b));
+    hipStream_t st = as_stream(stream);
+    if (vec) {
+        if (b)
+            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb, out,
+                               n);
+        else
+            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb,
+                               out, n);
+    } else {
+        if (b)
+            hipLaunchKernelGGL((axpby_kernel<false, true>), dim3(blocks_for(n)), dim3(256), 0, st, a, ca, b, cb, out, n);
+        else
+            hipLaunchKernelGGL((axpby_kernel<false, false>), dim3(blocks_for(n)), dim3(256), 0, st, a, ca, b, cb, out,
+                               n);
+    }
+    return check_launch("axpby");
+}
+
+extern "C" int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out, int B, size_t per,
+                                void* stream) {
+    EEGGAN_REQUIRE(real && fake && mix && out && B > 0 && per > 0, "mix_batch: null pointer or empty");
+    const size_t n = (size_t)B * per;
+    hipLaunchKernelGGL(mix_batch_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), real, fake, mix, out, n,
+                       per);
+    return check_launch("mix_batch");
+}
+
+extern "C" int eeggan_pow_base(const float* x, float* out, size_t count, float base, void* stream) {
+    EEGGAN_REQUIRE(x && out && count > 0 && base > 0.f, "pow_base: bad argument");
+    hipLaunchKernelGGL(pow_base_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, out, count,
+                       logf(base));
+    return check_launch("pow_base");
+}

@@ -1,0 +1,357 @@
+// The two full-length-kernel layers of the path, which are dense matrix products rather
+// than sliding convolutions:
+//   G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal  == [B,Cin] x [Cin, Cout*KT]
+//   D tail: Conv1d(k=KT, pad=0)    on a length-KT signal == [B,Cin*KT] x [Cin*KT, Cout]
+// At the path's sizes (B <= 512, Cin = Cout = 256, KT = 32) they move the 8.4 MB weight
+// once and do ~0.1-2 GFLOP: bandwidth/latency-bound, so they are plain fp32 VALU kernels
+// with the weight streamed coalesced and the small operand broadcast from LDS.
+#include "common.h"
+
+namespace eeggan {
+namespace {
+
+__device__ __forceinline__ float apply_act(float v, int act, float p) {
+    if (act == EEGGAN_ACT_LRELU) return v > 0.f ? v : v * p;
+    if (act == EEGGAN_ACT_TANH) return tanhf(v * p);
+    return v;
+}
+
+// ---- head forward: grid (Cout, ceil(B/32)), 256 threads = 32 taps x 8 sample lanes ------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ drop,
+                                                       float* __restrict__ y, int B, int Cin, int Cout, int KT,
+                                                       float in_scale, int act, float act_param) {
+    extern __shared__ float zs[];  // [32][Cin]
+    const int co = blockIdx.x;
+    const int b0 = blockIdx.y * 32;
+    for (int i = threadIdx.x; i < 32 * Cin; i += 256) {
+        const int bl = i / Cin, ci = i - bl * Cin;
+        zs[i] = (b0 + bl < B) ? z[(long long)(b0 + bl) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    const int tp = threadIdx.x & 31, bq = threadIdx.x >> 5;
+    const float bv = bias ? bias[co] : 0.f;
+    for (int t0 = 0; t0 < KT; t0 += 32) {
+        const int tw = t0 + tp;  // weight tap index; output time = KT-1-tw
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tw < KT) {
+            const float* wp = w + (long long)co * Cin * KT + tw;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float wv = wp[(long long)ci * KT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += wv * zs[(bq + 8 * i) * Cin + ci];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + bq + 8 * i;
+                if (b < B) {
+                    float v = apply_act(acc[i] * in_scale + bv, act, act_param);
+                    if (drop) v *= drop[b * Cout + co];
+                    y[((long long)b * Cout + co) * KT + (KT - 1 - tw)] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- head wgrad: grid (Cout, ceil(Cin/64)), threads = 32 taps x 8 channel lanes ------------------
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ z, const float* __restrict__ gy,
+                                                         float* __restrict__ gw, float* __restrict__ gb, int B, int Cin,
+                                                         int Cout, int KT, float in_scale) {
+    __shared__ float gsh[32][33];
+    __shared__ float zsh[32][64];
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    const int ci0 = blockIdx.y * 64;
+    const int tp = threadIdx.x & 31, cq = threadIdx.x >> 5;
+    float bsum = 0.f;
+    for (int t0 = 0; t0 < KT; t0 += 32) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 32) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+                const int bl = i >> 5, tt = i & 31;  // tt = weight tap offset; time = KT-1-(t0+tt)
+                const int tw = t0 + tt;
+                float v = 0.f;
+                if (b0 + bl < B && tw < KT) v = gy[((long long)(b0 + bl) * Cout + co) * KT + (KT - 1 - tw)];
+                gsh[bl][tt] = v;
+                bsum += v;
+            }
+            for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+                const int bl = i >> 6, cl = i & 63;
+                zsh[bl][cl] = (b0 + bl < B && ci0 + cl < Cin) ? z[(long long)(b0 + bl) * Cin + ci0 + cl] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int bl = 0; bl < 32; ++bl) {
+                const float g = gsh[bl][tp];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += g * zsh[bl][cq + 8 * i];
+            }
+        }
+        const int tw = t0 + tp;
+        if (tw < KT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = ci0 + cq + 8 * i;
+                if (ci < Cin) gw[((long long)co * Cin + ci) * KT + tw] = acc[i] * in_scale;
+            }
+        }
+    }
+    if (gb && blockIdx.y == 0) {
+        const float tot = block_sum_256(bsum, red);
+        if (threadIdx.x == 0) gb[co] = tot;
+    }
+}
+
+// ---- head dgrad: grid (Cin, ceil(B/32)) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                         float* __restrict__ gz, int B, int Cin, int Cout, int KT,
+                                                         float in_scale) {
+    const int ci = blockIdx.x;
+    const int b0 = blockIdx.y * 32;
+    const int tp = threadIdx.x & 31, bq = threadIdx.x >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < KT; t0 += 32) {
+        const int tw = t0 + tp;
+        if (tw >= KT) continue;
+        for (int co = 0; co < Cout; ++co) {
+            const float wv = w[((long long)co * Cin + ci) * KT + tw];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + bq + 8 * i;
+                if (b < B) acc[i] += wv * gy[((long long)b * Cout + co) * KT + (KT - 1 - tw)];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const int b = b0 + bq + 8 * i;
+        if (tp == 0 && b < B) gz[(long long)b * Cin + ci] = v * in_scale;
+    }
+}
+
+// ---- tail forward: grid (ceil(Cout/4), ceil(B/8)); every thread strides the reduction axis ------
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ drop,
+                                                       float* __restrict__ y, int B, int Kd, int Cout, float in_scale,
+                                                       int act, float act_param) {
+    __shared__ float red[4][32];
+    const int co0 = blockIdx.x * 4;
+    const int b0 = blockIdx.y * 8;
+    float acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int k = threadIdx.x * 4; k < Kd; k += 1024) {
+        f32x4 wv[4], xv[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + i < Cout ? co0 + i : Cout - 1;
+            wv[i] = *reinterpret_cast<const f32x4*>(w + (long long)co * Kd + k);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j < B ? b0 + j : B - 1;
+            xv[j] = *reinterpret_cast<const f32x4*>(x + (long long)b * Kd + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i][j] += (wv[i][0] * xv[j][0] + wv[i][1] * xv[j][1]) + (wv[i][2] * xv[j][2] + wv[i][3] * xv[j][3]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = wave_sum(acc[i][j]);
+            if (lane == 0) red[wave][i * 8 + j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int i = threadIdx.x >> 3, j = threadIdx.x & 7;
+        const int co = co0 + i, b = b0 + j;
+        if (co < Cout && b < B) {
+            float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+            v = apply_act(v * in_scale + (bias ? bias[co] : 0.f), act, act_param);
+            if (drop) v *= drop[b * Cout + co];
+            y[(long long)b * Cout + co] = v;
+        }
+    }
+}
+
+// ---- tail dgrad: grid (ceil(Kd/256), ceil(B/8)); 4 channel groups x 64 float4 columns -----------
+__global__ __launch_bounds__(256) void tail_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                         float* __restrict__ gx, int B, int Kd, int Cout,
+                                                         float in_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gsh = sm;                    // [8][Cout]
+    f32x4* part = reinterpret_cast<f32x4*>(sm + ((8 * Cout + 3) & ~3));  // [4][8][64]
+    const int b0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < 8 * Cout; i += 256) {
+        const int j = i / Cout, co = i - j * Cout;
+        gsh[i] = (b0 + j < B) ? gy[(long long)(b0 + j) * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int k = blockIdx.x * 256 + l * 4;
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k < Kd) {
+        for (int co = cg; co < Cout; co += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long long)co * Kd + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = gsh[j * Cout + co];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] += g * wv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[(cg * 8 + j) * 64 + l] = acc[j];
+    __syncthreads();
+    // 8 samples x 64 columns = 512 float4 results, 2 per thread
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int j = i >> 6, ll = i & 63;
+        const int kk = blockIdx.x * 256 + ll * 4;
+        if (b0 + j < B && kk < Kd) {
+            f32x4 s = part[(0 * 8 + j) * 64 + ll];
+#pragma unroll
+            for (int g = 1; g < 4; ++g) {
+                const f32x4 p = part[(g * 8 + j) * 64 + ll];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += p[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] *= in_scale;
+            *reinterpret_cast<f32x4*>(gx + (long long)(b0 + j) * Kd + kk) = s;
+        }
+    }
+}
+
+// ---- tail wgrad: grid (ceil(Kd/1024), ceil(Cout/8)) ------------------------------------------------
+__global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                         float* __restrict__ gw, float* __restrict__ gb, int B, int Kd,
+                                                         int Cout, float in_scale) {
+    extern __shared__ float gsh[];  // [B][8]
+    const int co0 = blockIdx.y * 8;
+    for (int i = threadIdx.x; i < B * 8; i += 256) {
+        const int b = i >> 3, c = i & 7;
+        gsh[i] = (co0 + c < Cout) ? gy[(long long)b * Cout + co0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 1024 + threadIdx.x * 4;
+    if (k < Kd) {
+        f32x4 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)b * Kd + k);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float g = gsh[b * 8 + c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][e] += g * xv[e];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (co0 + c < Cout) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[c][e] * in_scale;
+                *reinterpret_cast<f32x4*>(gw + (long long)(co0 + c) * Kd + k) = o;
+            }
+        }
+    }
+    if (gb && blockIdx.x == 0 && threadIdx.x < 8 && co0 + threadIdx.x < Cout) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += gsh[b * 8 + threadIdx.x];
+        gb[co0 + threadIdx.x] = s;
+    }
+}
+
+int check_ht(const char* what, int B, int Cin, int Cout, int KT) {
+    EEGGAN_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && KT > 0, "%s: non-positive dimension", what);
+    EEGGAN_REQUIRE(B <= 4096, "%s: batch %d above the supported 4096", what, B);
+    EEGGAN_REQUIRE((long long)Cin * KT * (long long)(Cout > B ? Cout : B) < (1ll << 31), "%s: operand too large", what);
+    return 0;
+}
+
+}  // namespace
+}  // namespace eeggan
+
+using namespace eeggan;
+
+extern "C" int eeggan_head_fwd(const float* z, const float* w, const float* bias, const float* drop, float* y, int B,
+                               int Cin, int Cout, int KT, float in_scale, int act, float act_param, void* stream) {
+    if (check_ht("head_fwd", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(z && w && y, "head_fwd: null pointer");
+    EEGGAN_REQUIRE(Cin <= 384, "head_fwd: Cin %d above the supported 384 (LDS tile)", Cin);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(Cout, (B + 31) / 32), dim3(256), (size_t)32 * Cin * sizeof(float),
+                       as_stream(stream), z, w, bias, drop, y, B, Cin, Cout, KT, in_scale, act, act_param);
+    return check_launch("head_fwd");
+}
+
+extern "C" int eeggan_head_wgrad(const float* z, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
+                                 int KT, float in_scale, void* stream) {
+    if (check_ht("head_wgrad", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(z && gy && gw, "head_wgrad: null pointer");
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, as_stream(stream), z, gy, gw, gb,
+                       B, Cin, Cout, KT, in_scale);
+    return check_launch("head_wgrad");
+}
+
+extern "C" int eeggan_head_dgrad(const float* gy, const float* w, float* gz, int B, int Cin, int Cout, int KT,
+                                 float in_scale, void* stream) {
+    if (check_ht("head_dgrad", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(gy && w && gz, "head_dgrad: null pointer");
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3(Cin, (B + 31) / 32), dim3(256), 0, as_stream(stream), gy, w, gz, B, Cin,
+                       Cout, KT, in_scale);
+    return check_launch("head_dgrad");
+}
+
+extern "C" int eeggan_tail_fwd(const float* x, const float* w, const float* bias, const float* drop, float* y, int B,
+                               int Cin, int Cout, int KT, float in_scale, int act, float act_param, void* stream) {
+    if (check_ht("tail_fwd", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(x && w && y, "tail_fwd: null pointer");
+    const int Kd = Cin * KT;
+    EEGGAN_REQUIRE(Kd % 4 == 0, "tail_fwd: Cin*KT = %d must be a multiple of 4", Kd);
+    hipLaunchKernelGGL(tail_fwd_kernel, dim3((Cout + 3) / 4, (B + 7) / 8), dim3(256), 0, as_stream(stream), x, w, bias,
+                       drop, y, B, Kd, Cout, in_scale, act, act_param);
+    return check_launch("tail_fwd");
+}
+
+extern "C" int eeggan_tail_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, int Cout, int KT,
+                                 float in_scale, void* stream) {
+    if (check_ht("tail_dgrad", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(gy && w && gx, "tail_dgrad: null pointer");
+    const int Kd = Cin * KT;
+    EEGGAN_REQUIRE(Kd % 4 == 0, "tail_dgrad: Cin*KT = %d must be a multiple of 4", Kd);
+    EEGGAN_REQUIRE(Cout <= 1024, "tail_dgrad: Cout %d above the supported 1024 (LDS tile)", Cout);
+    const size_t lds = ((size_t)((8 * Cout + 3) & ~3) + 4 * 8 * 64 * 4) * sizeof(float);
+    hipLaunchKernelGGL(tail_dgrad_kernel, dim3((Kd + 255) / 256, (B + 7) / 8), dim3(256), lds, as_stream(stream), gy, w,
+                       gx, B, Kd, Cout, in_scale);
+    return check_launch("tail_dgrad");
+}
+
+extern "C" int eeggan_tail_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
+                                 int KT, float in_scale, void* stream) {
+    if (check_ht("tail_wgrad", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(x && gy && gw, "tail_wgrad: null pointer");
+    const int Kd = Cin * KT;
+    EEGGAN_REQUIRE(Kd % 4 == 0, "tail_wgrad: Cin*KT = %d must be a multiple of 4", Kd);
+    hipLaunchKernelGGL(tail_wgrad_kernel, dim3((Kd + 1023) / 1024, (Cout + 7) / 8), dim3(256),
+                       (size_t)B * 8 * sizeof(float), as_stream(stream), x, gy, gw, gb, B, Kd, Cout, in_scale);
+    return check_launch("tail_wgrad");
+}

@@ -1,0 +1,237 @@
+// Rational resampler (one sparse-row gather kernel for both directions) and the
+// MinibatchStddev layer with its first- and second-order backward.
+#include "common.h"
+
+namespace eeggan {
+namespace {
+
+// ---- resample -----------------------------------------------------------------------------------
+// Thread = one output position m for ROWS_PER_BLOCK consecutive rows; its taps stay in registers.
+constexpr int RS_ROWS = 8;
+constexpr int RS_MAXTAPS = 16;
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                       const float* __restrict__ coef, float* __restrict__ out,
+                                                       long long rows, int Tin, int Tout) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Tout) return;
+    int ii[TAPS];
+    float cc[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+        ii[k] = idx[m * TAPS + k];
+        cc[k] = coef[m * TAPS + k];
+    }
+    const long long r0 = (long long)blockIdx.y * RS_ROWS;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        const long long row = r0 + r;
+        if (row < rows) {
+            const float* xr = x + row * Tin;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) s += cc[k] * xr[ii[k]];
+            out[row * Tout + m] = s;
+        }
+    }
+}
+
+// ---- minibatch stddev --------------------------------------------------------------------------
+// One workgroup per group member m; its G samples are b = g*M + m.  n = C*T elements per sample.
+constexpr int MB_MAXG = 8;
+
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int M,
+                                                        int G, int C, int T) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const int n = C * T;
+    const float invG = 1.f / (float)G;
+    float ssum = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        float v[MB_MAXG];
+        float mu = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                v[g] = x[((long long)(g * M + m)) * n + e];
+                mu += v[g];
+            }
+        mu *= invG;
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const float d = v[g] - mu;
+                var += d * d;
+                out[((long long)(g * M + m)) * (n + T) + e] = v[g];  // channels [0, C) are a copy of x
+            }
+        ssum += sqrtf(var * invG);
+    }
+    const float s = block_sum_256(ssum, red) / (float)n;
+    for (int i = threadIdx.x; i < G * T; i += 256) {
+        const int g = i / T, t = i - g * T;
+        out[((long long)(g * M + m)) * (n + T) + n + t] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                        float* __restrict__ gx, int M, int G, int C, int T) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const int n = C * T;
+    const float invG = 1.f / (float)G;
+    float gs = 0.f;
+    for (int i = threadIdx.x; i < G * T; i += 256) {
+        const int g = i / T, t = i - g * T;
+        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
+    }
+    const float a = block_sum_256(gs, red) / ((float)n * (float)G);
+    for (int e = threadIdx.x; e < n; e += 256) {
+        float v[MB_MAXG];
+        float mu = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                v[g] = x[((long long)(g * M + m)) * n + e];
+                mu += v[g];
+            }
+        mu *= invG;
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const float d = v[g] - mu;
+                var += d * d;
+            }
+        const float inv_sigma = 1.f / sqrtf(var * invG);
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const long long b = g * M + m;
+                gx[b * n + e] = gout[b * (n + T) + e] + a * (v[g] - mu) * inv_sigma;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                            const float* __restrict__ q, float* __restrict__ ggout,
+                                                            float* __restrict__ gx2, int M, int G, int C, int T) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const int n = C * T;
+    const float invG = 1.f / (float)G;
+    float gs = 0.f;
+    for (int i = threadIdx.x; i < G * T; i += 256) {
+        const int g = i / T, t = i - g * T;
+        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
+    }
+    const float a = block_sum_256(gs, red) / ((float)n * (float)G);
+    float dsum = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        float v[MB_MAXG], qv[MB_MAXG];
+        float mu = 0.f, qm = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const long long b = g * M + m;
+                v[g] = x[b * n + e];
+                qv[g] = q[b * n + e];
+                mu += v[g];
+                qm += qv[g];
+            }
+        mu *= invG;
+        qm *= invG;
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const float d = v[g] - mu;
+                var += d * d;
+            }
+        const float inv_sigma = 1.f / sqrtf(var * invG);
+        float qr = 0.f;  // sum_g q_g * R_g
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) qr += qv[g] * (v[g] - mu) * inv_sigma;
+        dsum += qr;
+        const float qrm = qr * invG;
+#pragma unroll
+        for (int g = 0; g < MB_MAXG; ++g)
+            if (g < G) {
+                const long long b = g * M + m;
+                const float R = (v[g] - mu) * inv_sigma;
+                gx2[b * n + e] = a * inv_sigma * ((qv[g] - qm) - R * qrm);
+                ggout[b * (n + T) + e] = qv[g];
+            }
+    }
+    const float dtot = block_sum_256(dsum, red) / ((float)n * (float)G);
+    for (int i = threadIdx.x; i < G * T; i += 256) {
+        const int g = i / T, t = i - g * T;
+        ggout[((long long)(g * M + m)) * (n + T) + n + t] = dtot;
+    }
+}
+
+int mb_check(const char* what, int B, int C, int T, int group, int* G, int* M) {
+    EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0 && group > 0, "%s: non-positive argument", what);
+    *G = B < group ? B : group;
+    EEGGAN_REQUIRE(*G <= MB_MAXG, "%s: group size %d above the supported %d", what, *G, MB_MAXG);
+    EEGGAN_REQUIRE(B % *G == 0, "%s: batch %d not divisible by group size %d", what, B, *G);
+    EEGGAN_REQUIRE((long long)C * T < (1ll << 24), "%s: C*T too large", what);
+    *M = B / *G;
+    return 0;
+}
+
+}  // namespace
+}  // namespace eeggan
+
+using namespace eeggan;
+
+extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float* out, size_t rows, int Tin,
+                               int Tout, int taps, void* stream) {
+    EEGGAN_REQUIRE(x && idx && coef && out, "resample: null pointer");
+    EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample: non-positive dimension");
+    EEGGAN_REQUIRE(taps >= 1 && taps <= RS_MAXTAPS, "resample: taps %d outside [1, %d]", taps, RS_MAXTAPS);
+    const size_t gy = (rows + RS_ROWS - 1) / RS_ROWS;
+    EEGGAN_REQUIRE(gy <= 65535u * 1024u, "resample: too many rows");
+    dim3 grid((Tout + 255) / 256, (unsigned)gy);
+    hipStream_t st = as_stream(stream);
+#define RS_CASE(N)                                                                                              \
+    case N:                                                                                                     \
+        hipLaunchKernelGGL(resample_kernel<N>, grid, dim3(256), 0, st, x, idx, coef, out, (long long)rows, Tin, \
+                           Tout);                                                                               \
+        break;
+    switch (taps) {
+        RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+        RS_CASE(9) RS_CASE(10) RS_CASE(11) RS_CASE(12) RS_CASE(13) RS_CASE(14) RS_CASE(15) RS_CASE(16)
+    }
+#undef RS_CASE
+    return check_launch("resample");
+}
+
+extern "C" int eeggan_mbstd_fwd(const float* x, float* out, int B, int C, int T, int group, void* stream) {
+    int G, M;
+    if (mb_check("mbstd_fwd", B, C, T, group, &G, &M)) return 1;
+    EEGGAN_REQUIRE(x && out, "mbstd_fwd: null pointer");
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, out, M, G, C, T);
+    return check_launch("mbstd_fwd");
+}
+
+extern "C" int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
+                                void* stream) {
+    int G, M;
+    if (mb_check("mbstd_bwd", B, C, T, group, &G, &M)) return 1;
+    EEGGAN_REQUIRE(x && gout && gx, "mbstd_bwd: null pointer");
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, gout, gx, M, G, C, T);
+    return check_launch("mbstd_bwd");
+}
+
+extern "C" int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2, int B,
+                                    int C, int T, int group, void* stream) {
+    int G, M;
+    if (mb_check("mbstd_bwd_bwd", B, C, T, group, &G, &M)) return 1;
+    EEGGAN_REQUIRE(x && gout && q && ggout && gx2, "mbstd_bwd_bwd: null pointer");
+    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, gout, q, ggout, gx2, M, G, C,
+                       T);
+    return check_launch("mbstd_bwd_bwd");
+}

@@ -1,0 +1,216 @@
+"""Layer modules with the names, constructor signatures and state-dict layout of the reference's
+``layers.py``; every forward runs fused HIP kernels (see ``ops.py``).
+
+Supported: the options the default configuration uses (reference defaults.yml:16-58).  Options
+outside that set (spectral norm, separable convs, conditional batch norm, self attention, the
+residual helpers) raise ``NotImplementedError`` at construction: there is no second code path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn.init import calculate_gain
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE
+from .utils import pixel_norm
+
+# How GDropLayer draws its multipliers:
+#   'numpy'  - from the global numpy RNG on the host, fp64, exactly like the reference
+#              (layers.py:32-38): identical seeds give identical multipliers;
+#   'device' - N(0,1) drawn on the device (no host round trip; graph-capturable); same
+#              distribution, different stream.
+_drop_mode = "numpy"
+
+
+def set_drop_mode(mode: str) -> None:
+    global _drop_mode
+    if mode not in ("numpy", "device"):
+        raise ValueError(mode)
+    _drop_mode = mode
+
+
+def get_drop_mode() -> str:
+    return _drop_mode
+
+
+class PixelNorm(nn.Module):
+    def forward(self, x):
+        return pixel_norm(x)
+
+
+class ScaledTanh(nn.Tanh):
+    """tanh(scale * x).  On the path it is always the epilogue of a to_rgb conv and is fused there."""
+
+    def __init__(self, scale=0.5):
+        super().__init__()
+        self.scale = scale
+
+    def forward(self, x):
+        raise NotImplementedError("ScaledTanh runs fused into the preceding GeneralConv (see network.ToRgb)")
+
+
+class GDropLayer(nn.Module):
+    """Multiplicative log-normal noise shared over time: x * (1+strength)**N(0,1)[B, C, 1]."""
+
+    def __init__(self, strength=0.2, axes=(0, 1)):
+        super().__init__()
+        self.strength = strength
+        self.axes = [axes] if isinstance(axes, int) else list(axes)
+        if sorted(self.axes) != [0, 1]:
+            raise NotImplementedError("GDropLayer: only per-(sample, channel) noise (axes=(0, 1)) is supported")
+
+    def sample(self, batch, channels, device):
+        """Multipliers [B, C] (float32, on `device`) or None when the layer is off."""
+        if not self.strength:
+            return None
+        if _drop_mode == "numpy":
+            rnd = (1 + self.strength) ** np.random.normal(size=[batch, channels, 1])
+            return torch.from_numpy(rnd.astype(np.float32).reshape(batch, channels)).to(device)
+        n = torch.randn((batch, channels), device=device, dtype=torch.float32)
+        return ops.pow_base_raw(n, 1.0 + self.strength)
+
+    def forward(self, x, deterministic=False):
+        if deterministic or not self.strength:
+            return x
+        r = self.sample(x.shape[0], x.shape[1], x.device)
+        return ops._MaskMul.apply(x, x, r, 1.0)
+
+
+class MinibatchStddev(nn.Module):
+    def __init__(self, group_size=4, temporal_groups_per_window=1, kernel_size=32):
+        super().__init__()
+        self.group_size = group_size if group_size != 0 else 1e6
+        self.kernel_size = kernel_size
+        self.stride_size = self.kernel_size // temporal_groups_per_window
+
+    def forward(self, x):
+        if self.group_size < 0:
+            return x
+        if x.shape[2] > self.stride_size:
+            raise NotImplementedError("MinibatchStddev: more than one temporal window is not supported")
+        return ops.minibatch_stddev(x, int(min(x.shape[0], self.group_size)))
+
+
+def _unsupported(name):
+    class _Unsupported(nn.Module):
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError(f"{name} is outside the accelerated default configuration")
+
+    _Unsupported.__name__ = name
+    return _Unsupported
+
+
+SelfAttention = _unsupported("SelfAttention")
+ConditionalBatchNorm = _unsupported("ConditionalBatchNorm")
+EqualizedSeparableConv1d = _unsupported("EqualizedSeparableConv1d")
+PassChannelResidual = _unsupported("PassChannelResidual")
+ConcatResidual = _unsupported("ConcatResidual")
+
+
+class EqualizedConv1d(nn.Module):
+    """Conv1d whose INPUT is multiplied by the RMS of the freshly initialised weight; the stored
+    weight is that init divided by its RMS (reference layers.py:150-174).  ``self.conv`` is an
+    ``nn.Conv1d`` used as the parameter container, so state-dict keys and the RNG stream consumed
+    at construction match the reference; its own forward is never called."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding, spectral, equalized, init, act_alpha, bias,
+                 groups, stride):
+        super().__init__()
+        if spectral or groups != 1 or stride != 1:
+            raise NotImplementedError("EqualizedConv1d: spectral norm, groups and strides are not supported")
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias,
+                              groups=groups)
+        w = self.conv.weight
+        with torch.no_grad():
+            if bias:
+                self.conv.bias.zero_()
+            slope = act_alpha if act_alpha > 0 else 1
+            if init == "kaiming_normal":
+                nn.init.kaiming_normal_(w, a=slope)
+            elif init == "xavier_uniform":
+                nn.init.xavier_uniform_(w, gain=calculate_gain("leaky_relu", param=slope))
+            elif init == "orthogonal":
+                nn.init.orthogonal_(w, gain=calculate_gain("leaky_relu", param=slope))
+            self.scale = (torch.mean(w ** 2) ** 0.5).item() if equalized else 1.0
+            w.copy_(w / self.scale)
+        self.kernel_size = kernel_size
+        self.padding = padding
+
+    def kind(self, x):
+        k, pad = self.kernel_size, self.padding
+        if k in (1, 3) and pad == (k - 1) // 2:
+            return "same"
+        if pad == k - 1 and x.shape[2] == 1:
+            return "head"
+        if pad == 0 and x.shape[2] == k:
+            return "tail"
+        raise NotImplementedError(f"conv with kernel_size={k}, padding={pad} on length {x.shape[2]} is not supported")
+
+    def forward(self, x):
+        if self.kind(x) != "same":
+            raise NotImplementedError("a bare full-length conv is only available fused inside GeneralConv")
+        return ops.conv1d(x, self.conv.weight, self.conv.bias, None, self.scale, ACT_NONE)
+
+
+class GeneralConv(nn.Module):
+    """conv -> (LeakyReLU) -> (PixelNorm) -> (GDrop), executed as one or two fused kernels.
+
+    The discriminator form (no norm) is twice differentiable; the generator form (pixel norm or
+    the to_rgb tanh) supports a first-order backward, which is all the training step asks of it."""
+
+    def __init__(self, in_channels, out_channels, z_to_bn_size=0, kernel_size=3, equalized=True, pad=None,
+                 act_alpha=0.2, do=0, num_classes=0, act_norm=None, spectral=False, init="kaiming_normal", bias=True,
+                 separable=False, stride=1):
+        super().__init__()
+        if separable or act_norm == "batch" or act_norm not in (None, "pixel"):
+            raise NotImplementedError("GeneralConv: separable convs and act_norm other than None/'pixel' "
+                                      "are not supported")
+        pad = (kernel_size - 1) // 2 if pad is None else pad
+        self.conv = EqualizedConv1d(in_channels, out_channels, kernel_size, padding=pad, spectral=spectral,
+                                    equalized=equalized, init=init, act_alpha=act_alpha, bias=bias, groups=1,
+                                    stride=stride)
+        self.norm = None
+        self.act_alpha = act_alpha
+        self.act_norm = act_norm
+        net = []
+        if act_alpha >= 0:
+            net.append(nn.ReLU() if act_alpha == 0 else nn.LeakyReLU(act_alpha))
+        if act_norm == "pixel":
+            net.append(PixelNorm())
+        self.drop = GDropLayer(strength=do) if do != 0 else None
+        if self.drop is not None:
+            net.append(self.drop)
+        self.net = nn.Sequential(*net)  # parameter-less; kept for module-tree parity
+
+    def _multipliers(self, x):
+        if self.drop is None:
+            return None
+        return self.drop.sample(x.shape[0], self.conv.conv.out_channels, x.device)
+
+    def forward(self, x, y=None, z=None, conv_noise=None, _tanh_scale=None):
+        if conv_noise is not None:
+            raise NotImplementedError("per-channel conv noise is not supported")
+        c = self.conv
+        w, b, s = c.conv.weight, c.conv.bias, c.scale
+        kind = c.kind(x)
+        slope = float(max(self.act_alpha, 0.0))
+        if _tanh_scale is not None:  # to_rgb: linear conv + tanh(scale * .)
+            if self.act_alpha >= 0 or self.act_norm is not None or self.drop is not None or kind != "same":
+                raise NotImplementedError("fused tanh epilogue needs a plain linear conv")
+            return ops.g_layer(x, w, b, None, s, 0.0, mode="tanh", kind="same", tanh_scale=_tanh_scale)
+        if self.act_norm == "pixel":
+            if self.act_alpha < 0 or kind == "tail":
+                raise NotImplementedError("pixel norm is fused with a (leaky-)ReLU same/head conv only")
+            xin = x.squeeze(2) if kind == "head" else x
+            return ops.g_layer(xin, w, b, self._multipliers(x), s, slope, mode="pn", kind=kind)
+        if self.act_alpha < 0:
+            if self.drop is not None or kind != "same":
+                raise NotImplementedError("linear conv with drop / full-length kernel is not supported")
+            return ops.conv1d(x, w, b, None, s, ACT_NONE)
+        if kind == "same":
+            return ops.conv1d(x, w, b, self._multipliers(x), s, ACT_LRELU, slope)
+        if kind == "tail":
+            return ops.tail_conv(x, w, b, self._multipliers(x), s, slope)
+        raise NotImplementedError("the length-1 (head) conv is only supported with pixel norm")

@@ -1,0 +1,96 @@
+"""``discriminator_loss`` / ``generator_loss`` / ``calc_grad`` with the signatures of the
+reference's ``losses.py`` (35-37, 40-70, 73-120) for the default ``wgan_gp`` loss.
+
+All reductions (means over the batch, the per-sample gradient norm and the penalty) run in
+fused HIP kernels; the gradient penalty differentiates through the discriminator's input
+gradient exactly as the reference does (``autograd.grad(..., create_graph=True)``).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+from torch.autograd import grad
+
+from . import ops
+from .utils import cudize
+
+one = None
+mixing_factors = None
+
+
+def get_mixing_factor(batch_size):
+    """A cached [B, 1, 1] buffer refilled with U[0, 1) at every call (reference losses.py:13-18)."""
+    global mixing_factors
+    if mixing_factors is None or batch_size != mixing_factors.size(0):
+        mixing_factors = cudize(torch.empty(batch_size, 1, 1, dtype=torch.float32))
+    mixing_factors.uniform_()
+    return mixing_factors
+
+
+def get_one(batch_size):
+    global one
+    if one is None or batch_size != one.size(0):
+        one = cudize(torch.ones(batch_size))
+    return one
+
+
+def calc_grad(x_hat, pred_hat):
+    """d(sum pred_hat)/d(x_hat) with a graph, so it can be differentiated again.  Weight
+    gradients are not formed in this pass (only the input gradient is asked for)."""
+    with ops.input_grad_only():
+        return grad(outputs=pred_hat, inputs=x_hat, grad_outputs=get_one(pred_hat.size(0)), create_graph=True,
+                    retain_graph=True, only_inputs=True)[0]
+
+
+@contextlib.contextmanager
+def _frozen(module: torch.nn.Module):
+    """Inside: the module's parameters do not require grad, so no weight gradients are formed for them."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    for p in params:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p in params:
+            p.requires_grad_(True)
+
+
+def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str, random_multiply: bool,
+                   feature_matching_lambda: float = 0.0, skip_dis_weight_grads: bool = True):
+    """-mean(D(G(z))).  ``skip_dis_weight_grads`` (default on) leaves ``dis`` parameters' ``.grad``
+    untouched: the reference accumulates them here only to zero them at the next discriminator
+    step (losses.py:75), so they are never used."""
+    if not (loss_type == "hinge" or loss_type.startswith("wgan")):
+        raise NotImplementedError(f"loss_type={loss_type!r}: only the wgan family is supported")
+    if random_multiply or feature_matching_lambda != 0.0:
+        raise NotImplementedError("random_multiply / feature matching are not supported")
+    gen.zero_grad()
+    g_, _ = gen(z)
+    with (_frozen(dis) if skip_dis_weight_grads else contextlib.nullcontext()):
+        d_fake, _, _ = dis(g_)
+    return ops.mean_scale(d_fake, -1.0)
+
+
+def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
+                       iwass_drift_epsilon: float, grad_lambda: float, iwass_target: float,
+                       mixing: Optional[torch.Tensor] = None):
+    """WGAN-GP critic loss.  ``mixing`` optionally supplies the per-sample interpolation factors
+    [B, 1, 1] (otherwise drawn like the reference does); used by parity tests."""
+    if loss_type != "wgan_gp":
+        raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
+    if grad_lambda == 0:
+        raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
+    dis.zero_grad()
+    d_real, _, _ = dis(real)
+    with torch.no_grad():
+        g_, _ = gen(z)
+    d_fake, _, _ = dis(g_)
+    real_x = real["x"] if isinstance(real, dict) else real
+    fake_x = g_["x"]
+    alpha = get_mixing_factor(real_x.size(0)) if mixing is None else mixing
+    x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
+    pred_hat, _, _ = dis(x_hat)
+    g = calc_grad(x_hat["x"], pred_hat).view(real_x.size(0), -1)
+    return ops.wgan_gp_d_loss(d_real, d_fake, g, iwass_drift_epsilon, grad_lambda, iwass_target)

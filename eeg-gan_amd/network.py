@@ -1,0 +1,217 @@
+"""``Generator`` / ``Discriminator`` (and their blocks) with the constructor signatures,
+attributes and state-dict keys of the reference's ``network.py`` (GBlock 151-221,
+Generator 224-396, DBlock 399-449, Discriminator 452-560), running on the HIP kernels.
+
+Only the default configuration is accelerated; any other option raises
+``NotImplementedError`` in the constructor.  ``forward`` accepts either a tensor or the dict
+the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .layers import GeneralConv, MinibatchStddev, ScaledTanh
+from .utils import pixel_norm, resample_signal
+
+
+def _require(cond, what):
+    if not cond:
+        raise NotImplementedError(f"{what} is outside the accelerated default configuration")
+
+
+class ToRgb(nn.Sequential):
+    """[GeneralConv(k=1, linear), ScaledTanh]; runs as one conv kernel with a tanh epilogue."""
+
+    def forward(self, x):
+        return self[0](x, _tanh_scale=self[1].scale)
+
+
+class GBlock(nn.Module):
+    def __init__(self, ch_in, ch_out, ch_rgb, k_size=3, initial_kernel_size=None, is_residual=False, no_tanh=False,
+                 deep=False, per_channel_noise=False, to_rgb_mode="pggan", **layer_settings):
+        super().__init__()
+        _require(not is_residual and not deep and not per_channel_noise and not no_tanh and to_rgb_mode == "pggan",
+                 "GBlock(residual/deep/per_channel_noise/no_tanh/to_rgb_mode)")
+        first = initial_kernel_size is not None
+        self.convs = nn.ModuleList([
+            GeneralConv(ch_in, ch_out, kernel_size=initial_kernel_size if first else k_size,
+                        pad=initial_kernel_size - 1 if first else None, **layer_settings),
+            GeneralConv(ch_out, ch_out, kernel_size=k_size, **layer_settings)])
+        self.noises = None
+        rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
+        self.to_rgb = ToRgb(GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings), ScaledTanh())
+        self.residual = None
+        self.deep = False
+
+    def forward(self, x, y=None, z=None, last=False):
+        h = self.convs[1](self.convs[0](x))
+        return self.to_rgb(h) if last else h
+
+
+class Generator(nn.Module):
+    def __init__(self, initial_kernel_size, num_rgb_channels, fmap_base, fmap_max, fmap_min, kernel_size,
+                 self_attention_layers, progression_scale_up, progression_scale_down, residual, separable, equalized,
+                 init, act_alpha, num_classes, deep, z_distribution, spectral=False, latent_size=256, no_tanh=False,
+                 per_channel_noise=False, to_rgb_mode="pggan", z_to_bn=False, split_z=False, dropout=0.2,
+                 act_norm="pixel", conv_only=False, shared_embedding_size=32, normalize_latents=True,
+                 rgb_generation_mode="pggan"):
+        super().__init__()
+        _require(not self_attention_layers, "self attention")
+        _require(not residual and not separable and not deep and not spectral, "residual/separable/deep/spectral")
+        _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
+        _require(rgb_generation_mode == "pggan" and to_rgb_mode == "pggan" and not no_tanh and not per_channel_noise,
+                 "rgb_generation_mode/to_rgb_mode/no_tanh/per_channel_noise")
+        _require(act_norm in (None, "pixel"), f"act_norm={act_norm!r}")
+        assert len(progression_scale_up) == len(progression_scale_down)
+        stages = len(progression_scale_up)
+        self.progression_scale_up = progression_scale_up
+        self.progression_scale_down = progression_scale_down
+        self.depth = 0
+        self.alpha = 1.0
+        self.split_z = False
+        self.z_distribution = z_distribution
+        self.conv_only = False
+        self.initial_kernel_size = initial_kernel_size
+        self.normalize_latents = normalize_latents
+        self.z_to_bn = False
+
+        def nf(stage):
+            return min(max(int(fmap_base / (2.0 ** stage)), fmap_min), fmap_max)
+
+        if latent_size is None:
+            latent_size = nf(0)
+        self.input_latent_size = latent_size
+        self.latent_size = latent_size
+        self.y_encoder = None
+        block_settings = dict(ch_rgb=num_rgb_channels, k_size=kernel_size, is_residual=residual, deep=deep,
+                              no_tanh=no_tanh, per_channel_noise=per_channel_noise, to_rgb_mode=to_rgb_mode)
+        layer_settings = dict(z_to_bn_size=0, equalized=equalized, spectral=spectral, init=init, act_alpha=act_alpha,
+                              do=dropout, num_classes=num_classes, act_norm=act_norm, bias=True, separable=separable)
+        self.block0 = GBlock(latent_size, nf(1), initial_kernel_size=initial_kernel_size, **block_settings,
+                             **layer_settings)
+        self.self_attention = dict()
+        self.blocks = nn.ModuleList(
+            [GBlock(nf(i + 1), nf(i + 2), **block_settings, **layer_settings) for i in range(stages)])
+        self.max_depth = len(self.blocks)
+        self.deep = False
+        self.rgb_generation_mode = rgb_generation_mode
+
+    def _grow(self, h, stage):
+        return resample_signal(h, self.progression_scale_down[stage], self.progression_scale_up[stage])
+
+    def forward(self, z, y=None):
+        if isinstance(z, dict):
+            z = z["z"]
+        _require(y is None, "conditional generation")
+        if self.normalize_latents:
+            z = pixel_norm(z)
+        h = z.unsqueeze(2) if z.dim() == 2 else z
+        d = self.depth
+        if d == 0:
+            return {"x": self.block0(h, last=True), "y": None}, {}
+        h = self.block0(h)
+        for i in range(d - 1):
+            h = self.blocks[i](self._grow(h, i))
+        h = self._grow(h, d - 1)
+        ult = self.blocks[d - 1](h, last=True)
+        if self.alpha == 1.0:
+            return {"x": ult, "y": None}, {}
+        prev = self.blocks[d - 2] if d > 1 else self.block0
+        return {"x": ops.axpby(prev.to_rgb(h), 1.0 - self.alpha, ult, self.alpha), "y": None}, {}
+
+
+class DBlock(nn.Module):
+    def __init__(self, ch_in, ch_out, ch_rgb, sample_rate, k_size=3, initial_kernel_size=None, is_residual=False,
+                 deep=False, group_size=4, temporal_groups_per_window=1, conv_disc=False, sinc=False,
+                 **layer_settings):
+        super().__init__()
+        _require(not is_residual and not deep and not conv_disc and not sinc, "DBlock(residual/deep/conv_disc/sinc)")
+        last = initial_kernel_size is not None
+        stats = last and group_size >= 0
+        net = []
+        if stats:
+            net.append(MinibatchStddev(group_size, temporal_groups_per_window, initial_kernel_size))
+        net.append(GeneralConv(ch_in + (1 if stats else 0), ch_in, kernel_size=k_size, **layer_settings))
+        net.append(GeneralConv(ch_in, ch_out, kernel_size=initial_kernel_size if last else k_size,
+                               pad=0 if last else None, **layer_settings))
+        self.net = nn.Sequential(*net)
+        rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
+        self.from_rgb = GeneralConv(ch_rgb, ch_in, kernel_size=1, act_alpha=layer_settings["act_alpha"],
+                                    **rgb_settings)
+        self.residual = None
+        self.deep = False
+
+    def forward(self, x, first=False):
+        if first:
+            x = self.from_rgb(x)
+        return self.net(x)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, initial_kernel_size, num_rgb_channels, fmap_base, fmap_max, fmap_min, kernel_size,
+                 self_attention_layers, progression_scale_up, progression_scale_down, residual, separable, equalized,
+                 init, act_alpha, num_classes, deep, spectral=False, dropout=0.2, act_norm=None, group_size=4,
+                 temporal_groups_per_window=1, conv_only=False, input_to_all_layers=False, initial_sampling_rate=1.0,
+                 sinc=False):
+        super().__init__()
+        _require(not self_attention_layers, "self attention")
+        _require(not residual and not separable and not deep and not spectral, "residual/separable/deep/spectral")
+        _require(num_classes == 0 and not conv_only and not input_to_all_layers and not sinc,
+                 "conditioning/conv_only/input_to_all_layers/sinc")
+        _require(act_norm is None, "an activation norm in the discriminator")
+        assert len(progression_scale_up) == len(progression_scale_down)
+        stages = len(progression_scale_up)
+        self.progression_scale_up = progression_scale_up
+        self.progression_scale_down = progression_scale_down
+        self.depth = 0
+        self.alpha = 1.0
+        self.input_to_all_layers = False
+
+        def nf(stage):
+            return min(max(int(fmap_base / (2.0 ** stage)), fmap_min), fmap_max)
+
+        layer_settings = dict(equalized=equalized, spectral=spectral, init=init, act_alpha=act_alpha, do=dropout,
+                              num_classes=0, act_norm=act_norm, bias=True, separable=separable)
+        block_settings = dict(ch_rgb=num_rgb_channels, k_size=kernel_size, is_residual=residual, conv_disc=conv_only,
+                              group_size=group_size, temporal_groups_per_window=temporal_groups_per_window, deep=deep,
+                              sinc=sinc)
+        # the coarsest block is constructed first (it draws its initial weights first), then the
+        # others from fine to coarse, which end up at list positions 0 .. stages-1
+        last_block = DBlock(nf(1), nf(0), initial_kernel_size=initial_kernel_size,
+                            sample_rate=initial_sampling_rate, **block_settings, **layer_settings)
+        up, down = np.array(progression_scale_up), np.array(progression_scale_down)
+        lens = [initial_kernel_size * np.sum(up[:i] / down[:i]) for i in range(stages + 1)]
+        self.self_attention = dict()
+        self.blocks = nn.ModuleList(
+            [DBlock(nf(i + 2), nf(i + 1), sample_rate=lens[i + 1] * initial_sampling_rate / initial_kernel_size,
+                    **block_settings, **layer_settings) for i in range(stages - 1, -1, -1)] + [last_block])
+        self.class_emb = None
+        self.linear = GeneralConv(nf(0), 1, kernel_size=1, equalized=equalized, act_alpha=-1, spectral=spectral,
+                                  init=init)
+        self.max_depth = len(self.blocks) - 1
+
+    def _shrink(self, h, stage):
+        return resample_signal(h, self.progression_scale_up[stage], self.progression_scale_down[stage])
+
+    def forward(self, x, y=None):
+        if isinstance(x, dict):
+            x = x["x"]
+        _require(y is None, "conditional discrimination")
+        d = self.depth
+        h = self.blocks[-(d + 1)](x, True)
+        if d > 0:
+            h = self._shrink(h, d - 1)
+            if self.alpha < 1.0:
+                low = self.blocks[-d].from_rgb(self._shrink(x, d - 1))
+                h = ops.axpby(h, self.alpha, low, 1.0 - self.alpha)
+        for i in range(d, 0, -1):
+            h = self.blocks[-i](h)
+            if i > 1:
+                h = self._shrink(h, i - 2)
+        o = self.linear(h)
+        if o.shape[2] != 1:
+            o = resample_signal(o, o.shape[2], 1)  # mean over time as an average pool
+        return o.reshape(o.shape[0]), h, {}

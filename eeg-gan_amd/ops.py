@@ -1,0 +1,594 @@
+"""Autograd operators over the HIP kernels of ``libeeggan_hip.so``.
+
+PyTorch is used here for device memory (``torch.empty`` through the caching allocator),
+for the current HIP stream and for the autograd graph; every number is produced by a
+kernel of the shared library, called through its C ABI.  There is no fallback: tensors
+that are not float32 HIP tensors are rejected.
+
+Second-order support (needed by the WGAN-GP penalty, reference losses.py:35-37,113-118):
+the operators of the discriminator path build their backward out of other operators of
+this module, so ``autograd.grad(..., create_graph=True)`` followed by ``backward()`` works.
+Operators that only ever see a first-order backward on the path (generator layers, loss
+heads) raise if differentiated twice instead of returning wrong numbers.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_MASK, ACT_NONE, ACT_TANH, call
+
+# When set, backward passes skip weight/bias gradients.  Set around the create_graph pass of
+# the gradient penalty (only d(pred)/d(x_hat) is wanted there; reference losses.py:35-37).
+_input_grad_only = False
+
+
+@contextlib.contextmanager
+def input_grad_only():
+    global _input_grad_only
+    prev = _input_grad_only
+    _input_grad_only = True
+    try:
+        yield
+    finally:
+        _input_grad_only = prev
+
+
+# --------------------------------------------------------------------------------------- helpers
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a HIP device tensor, got {t.device}; this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------- raw kernels
+def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, act=ACT_NONE, act_param=0.0,
+               act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0):
+    x = _chk(x, "conv1d x")
+    w = _chk(w, "conv1d w")
+    B, Cin, T = x.shape
+    K = w.shape[2]
+    if transposed:
+        if w.shape[0] != Cin:
+            raise RuntimeError(f"conv1d(transposed): weight {tuple(w.shape)} does not match input channels {Cin}")
+        Cout = w.shape[1]
+    else:
+        if w.shape[1] != Cin:
+            raise RuntimeError(f"conv1d: weight {tuple(w.shape)} does not match input channels {Cin}")
+        Cout = w.shape[0]
+    for name, t, shape in (("bias", bias, (Cout,)), ("drop", drop, (B, Cout)), ("act_aux", act_aux, (B, Cout, T)),
+                           ("mask_y", mask_y, (B, Cin, T)), ("mask_drop", mask_drop, (B, Cin))):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32
+                              or not t.is_cuda):
+            raise RuntimeError(f"conv1d: {name} must be a contiguous float32 device tensor of shape {shape}, "
+                               f"got {tuple(t.shape)}")
+    y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    call("eeggan_conv1d", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, T, K,
+         float(in_scale), int(bool(transposed)), int(act), float(act_param), _p(act_aux), _p(mask_y), _p(mask_drop),
+         float(mask_slope), _stream())
+    return y
+
+
+def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mask_drop=None, mask_slope=0.0):
+    x = _chk(x, "wgrad x")
+    gy = _chk(gy, "wgrad gy")
+    B, Cin, T = x.shape
+    if gy.shape[0] != B or gy.shape[2] != T:
+        raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)} and gy {tuple(gy.shape)} disagree")
+    Cout = gy.shape[1]
+    for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
+            raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
+    nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    gw = torch.empty((Cout, Cin, K), device=x.device, dtype=torch.float32)
+    gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+    call("eeggan_conv1d_wgrad", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), _p(gb), B, Cin, Cout, T, K,
+         float(in_scale), _p(mask_y), _p(mask_drop), float(mask_slope), ws.data_ptr(), nbytes, _stream())
+    return gw, gb
+
+
+def lrelu_drop_bwd_raw(g, y, drop, slope):
+    g = _chk(g, "lrelu_drop_bwd g")
+    B, Cc, T = y.shape
+    out = torch.empty_like(y)
+    call("eeggan_lrelu_drop_bwd", g.data_ptr(), y.data_ptr(), _p(drop), out.data_ptr(), B, Cc, T, float(slope),
+         _stream())
+    return out
+
+
+def pixelnorm_drop_fwd_raw(h, drop, eps=1e-8):
+    h = _chk(h, "pixelnorm h")
+    B, Cc, T = h.shape
+    y = torch.empty_like(h)
+    d = torch.empty((B, T), device=h.device, dtype=torch.float32)
+    call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), _p(drop), y.data_ptr(), d.data_ptr(), B, Cc, T, float(eps),
+         _stream())
+    return y, d
+
+
+def pixelnorm_drop_bwd_raw(gy, y, drop, d, slope):
+    gy = _chk(gy, "pixelnorm gy")
+    B, Cc, T = y.shape
+    gc = torch.empty_like(y)
+    call("eeggan_pixelnorm_drop_bwd", gy.data_ptr(), y.data_ptr(), _p(drop), d.data_ptr(), gc.data_ptr(), B, Cc, T,
+         float(slope), _stream())
+    return gc
+
+
+def axpby_raw(a, ca, b=None, cb=0.0):
+    a = _chk(a, "axpby a")
+    if b is not None:
+        b = _chk(b, "axpby b")
+        if b.shape != a.shape:
+            raise RuntimeError(f"axpby: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty_like(a)
+    call("eeggan_axpby", a.data_ptr(), float(ca), _p(b), float(cb), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+def mix_batch_raw(real, fake, mix):
+    real = _chk(real, "mix real")
+    fake = _chk(fake, "mix fake")
+    mix = _chk(mix.reshape(-1), "mix factors")
+    if real.shape != fake.shape or mix.numel() != real.shape[0]:
+        raise RuntimeError("mix_batch: shape mismatch")
+    out = torch.empty_like(real)
+    call("eeggan_mix_batch", real.data_ptr(), fake.data_ptr(), mix.data_ptr(), out.data_ptr(), real.shape[0],
+         real[0].numel(), _stream())
+    return out
+
+
+def pow_base_raw(n, base):
+    n = _chk(n, "pow_base n")
+    out = torch.empty_like(n)
+    call("eeggan_pow_base", n.data_ptr(), out.data_ptr(), n.numel(), float(base), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------- D-path conv
+class _WGrad(Function):
+    """Weight/bias gradient; a leaf of the second-order graph (never differentiated on the path)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, K, in_scale, need_bias, mask_y, mask_drop, mask_slope):
+        gw, gb = conv1d_wgrad_raw(x, gy, K, in_scale=in_scale, need_bias=need_bias, mask_y=mask_y,
+                                  mask_drop=mask_drop, mask_slope=mask_slope)
+        if gb is None:
+            ctx.mark_non_differentiable()
+            return gw, None
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("third-order differentiation through the conv weight gradient is not supported")
+
+
+class _ConvT(Function):
+    """gx = in_scale * conv_transpose(mask(gy), w): input gradient of the fused conv layer,
+    itself differentiable w.r.t. gy and w (the double-backward of the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, mask_y, mask_drop, in_scale, slope):
+        gx = conv1d_raw(gy, w, None, None, in_scale=in_scale, transposed=True, mask_y=mask_y, mask_drop=mask_drop,
+                        mask_slope=slope)
+        ctx.save_for_backward(gy, w, mask_y, mask_drop)
+        ctx.in_scale, ctx.slope = in_scale, slope
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, q):
+        gy, w, mask_y, mask_drop = ctx.saved_tensors
+        q = _chk(q, "ConvT cotangent")
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            if mask_y is not None:
+                g_gy = conv1d_raw(q, w, None, mask_drop, in_scale=ctx.in_scale, act=ACT_MASK, act_param=ctx.slope,
+                                  act_aux=mask_y)
+            else:
+                g_gy = conv1d_raw(q, w, None, None, in_scale=ctx.in_scale)
+        if ctx.needs_input_grad[1] and not _input_grad_only:
+            g_w, _ = conv1d_wgrad_raw(q, gy, w.shape[2], in_scale=ctx.in_scale, need_bias=False, mask_y=mask_y,
+                                      mask_drop=mask_drop, mask_slope=ctx.slope)
+        return g_gy, g_w, None, None, None, None
+
+
+class _Conv(Function):
+    """y = drop * act(bias + conv(in_scale * x, w)), act in {none, leaky-relu}; twice differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, drop, in_scale, act, slope):
+        if act not in (ACT_NONE, ACT_LRELU):
+            raise ValueError("_Conv supports linear and leaky-relu epilogues")
+        if act == ACT_NONE and drop is not None:
+            raise ValueError("a drop multiplier needs the leaky-relu epilogue")
+        y = conv1d_raw(x, w, bias, drop, in_scale=in_scale, act=act, act_param=slope)
+        ctx.save_for_backward(x, w, drop, y if act == ACT_LRELU else None)
+        ctx.in_scale, ctx.slope, ctx.has_bias = in_scale, slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, drop, y = ctx.saved_tensors
+        gy = _chk(gy, "conv grad")
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvT.apply(gy, w, y, drop, ctx.in_scale, ctx.slope)
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
+            gw, gb = _WGrad.apply(x, gy, w.shape[2], ctx.in_scale, ctx.has_bias, y, drop, ctx.slope)
+        return gx, gw, gb, None, None, None, None
+
+
+def conv1d(x, w, bias, drop, in_scale, act, slope=0.0):
+    """Fused equalized conv layer of the discriminator path (twice differentiable)."""
+    return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope))
+
+
+# --------------------------------------------------------------------------------------- D tail
+class _MaskMul(Function):
+    """out = g * drop * (y > 0 ? 1 : slope); linear in g, so its backward is itself."""
+
+    @staticmethod
+    def forward(ctx, g, y, drop, slope):
+        ctx.save_for_backward(y, drop)
+        ctx.slope = slope
+        return lrelu_drop_bwd_raw(g, y, drop, slope)
+
+    @staticmethod
+    def backward(ctx, q):
+        y, drop = ctx.saved_tensors
+        return _MaskMul.apply(_chk(q, "maskmul cotangent"), y, drop, ctx.slope), None, None, None
+
+
+def _tail_fwd_raw(x, w, bias, drop, in_scale, act, slope):
+    B, Cin, KT = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, Cout, 1), device=x.device, dtype=torch.float32)
+    call("eeggan_tail_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, KT,
+         float(in_scale), int(act), float(slope), _stream())
+    return y
+
+
+def _tail_dgrad_raw(gc, w, in_scale):
+    Cout, Cin, KT = w.shape
+    B = gc.shape[0]
+    gx = torch.empty((B, Cin, KT), device=gc.device, dtype=torch.float32)
+    call("eeggan_tail_dgrad", gc.data_ptr(), w.data_ptr(), gx.data_ptr(), B, Cin, Cout, KT, float(in_scale),
+         _stream())
+    return gx
+
+
+def _tail_wgrad_raw(x, gc, in_scale, need_bias):
+    B, Cin, KT = x.shape
+    Cout = gc.shape[1]
+    gw = torch.empty((Cout, Cin, KT), device=x.device, dtype=torch.float32)
+    gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+    call("eeggan_tail_wgrad", x.data_ptr(), gc.data_ptr(), gw.data_ptr(), _p(gb), B, Cin, Cout, KT, float(in_scale),
+         _stream())
+    return gw, gb
+
+
+class _TailWGrad(Function):
+    @staticmethod
+    def forward(ctx, x, gc, in_scale, need_bias):
+        gw, gb = _tail_wgrad_raw(_chk(x, "tail x"), _chk(gc, "tail gc"), in_scale, need_bias)
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("third-order differentiation through the tail weight gradient is not supported")
+
+
+class _TailT(Function):
+    """gx = in_scale * W^T gc for the full-length (k = T, pad = 0) layer; differentiable in gc and w."""
+
+    @staticmethod
+    def forward(ctx, gc, w, in_scale):
+        gc = _chk(gc, "tail gc")
+        ctx.save_for_backward(gc, w)
+        ctx.in_scale = in_scale
+        return _tail_dgrad_raw(gc, w, in_scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, q):
+        gc, w = ctx.saved_tensors
+        q = _chk(q, "tail cotangent")
+        g_gc = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gc = _tail_fwd_raw(q, w, None, None, ctx.in_scale, ACT_NONE, 0.0)
+        if ctx.needs_input_grad[1] and not _input_grad_only:
+            g_w, _ = _tail_wgrad_raw(q, gc, ctx.in_scale, False)
+        return g_gc, g_w, None
+
+
+class _Tail(Function):
+    """y[B, Cout, 1] = drop * lrelu(bias + sum_{ci,t} w[co,ci,t] * in_scale * x[b,ci,t]); twice differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, drop, in_scale, slope):
+        x = _chk(x, "tail x")
+        y = _tail_fwd_raw(x, w, bias, drop, in_scale, ACT_LRELU, slope)
+        ctx.save_for_backward(x, w, drop, y)
+        ctx.in_scale, ctx.slope, ctx.has_bias = in_scale, slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, drop, y = ctx.saved_tensors
+        gc = _MaskMul.apply(_chk(gy, "tail grad"), y, drop, ctx.slope)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _TailT.apply(gc, w, ctx.in_scale)
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
+            gw, gb = _TailWGrad.apply(x, gc, ctx.in_scale, ctx.has_bias)
+        return gx, gw, gb, None, None, None
+
+
+def tail_conv(x, w, bias, drop, in_scale, slope):
+    if x.shape[2] != w.shape[2]:
+        raise RuntimeError(f"tail conv: signal length {x.shape[2]} must equal the kernel size {w.shape[2]}")
+    return _Tail.apply(x, w, bias, drop, float(in_scale), float(slope))
+
+
+# --------------------------------------------------------------------------------------- G-path layers
+class _GLayer(Function):
+    """One generator layer, first-order differentiable:
+         mode 'pn'  : y = drop * pixelnorm(lrelu(bias + conv(x)))      (kind 'same' or 'head')
+         mode 'tanh': y = tanh(tanh_scale * (bias + conv(x)))           (to_rgb)
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, drop, in_scale, slope, mode, kind, tanh_scale):
+        x = _chk(x, "G layer x")
+        d = None
+        if kind == "head":
+            B, Cin = x.shape[0], x.shape[1]
+            Cout, _, KT = w.shape
+            h = torch.empty((B, Cout, KT), device=x.device, dtype=torch.float32)
+            call("eeggan_head_fwd", x.data_ptr(), w.data_ptr(), _p(bias), None, h.data_ptr(), B, Cin, Cout, KT,
+                 float(in_scale), ACT_LRELU, float(slope), _stream())
+            y, d = pixelnorm_drop_fwd_raw(h, drop)
+        elif mode == "pn":
+            h = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_LRELU, act_param=slope)
+            y, d = pixelnorm_drop_fwd_raw(h, drop)
+        elif mode == "tanh":
+            y = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_TANH, act_param=tanh_scale)
+        else:
+            raise ValueError(mode)
+        ctx.save_for_backward(x, w, drop, y, d)
+        ctx.cfg = (in_scale, slope, mode, kind, tanh_scale, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w, drop, y, d = ctx.saved_tensors
+        in_scale, slope, mode, kind, tanh_scale, has_bias = ctx.cfg
+        gy = _chk(gy, "G layer grad")
+        if mode == "tanh":
+            gc = torch.empty_like(y)
+            call("eeggan_tanh_bwd", gy.data_ptr(), y.data_ptr(), gc.data_ptr(), y.numel(), float(tanh_scale),
+                 _stream())
+        else:
+            gc = pixelnorm_drop_bwd_raw(gy, y, drop, d, slope)
+        gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        if kind == "head":
+            B, Cin = x.shape[0], x.shape[1]
+            Cout, _, KT = w.shape
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                call("eeggan_head_dgrad", gc.data_ptr(), w.data_ptr(), gx.data_ptr(), B, Cin, Cout, KT,
+                     float(in_scale), _stream())
+            if need_w:
+                gw = torch.empty_like(w)
+                gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if has_bias else None
+                call("eeggan_head_wgrad", x.data_ptr(), gc.data_ptr(), gw.data_ptr(), _p(gb), B, Cin, Cout, KT,
+                     float(in_scale), _stream())
+        else:
+            if ctx.needs_input_grad[0]:
+                gx = conv1d_raw(gc, w, None, None, in_scale=in_scale, transposed=True)
+            if need_w:
+                gw, gb = conv1d_wgrad_raw(x, gc, w.shape[2], in_scale=in_scale, need_bias=has_bias)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def g_layer(x, w, bias, drop, in_scale, slope, mode="pn", kind="same", tanh_scale=0.5):
+    return _GLayer.apply(x, w, bias, drop, float(in_scale), float(slope), mode, kind, float(tanh_scale))
+
+
+class _PixelNorm(Function):
+    @staticmethod
+    def forward(ctx, h):
+        y, d = pixelnorm_drop_fwd_raw(h, None)
+        ctx.save_for_backward(y, d)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        y, d = ctx.saved_tensors
+        return pixelnorm_drop_bwd_raw(gy, y, None, d, 1.0)
+
+
+def pixel_norm(h):
+    """h * rsqrt(mean_c h^2 + 1e-8) for [B, C] or [B, C, T] tensors."""
+    if h.dim() == 2:
+        return _PixelNorm.apply(h.unsqueeze(2)).squeeze(2)
+    return _PixelNorm.apply(h)
+
+
+# --------------------------------------------------------------------------------------- linear helpers
+class _Gather(Function):
+    """out[r, m] = sum_k coef[m, k] * x[r, idx[m, k]]; the backward is the same op with the transposed table."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        x = _chk(x, "resample x")
+        idx, coef, t_in, t_out, taps = fwd
+        if x.shape[-1] != t_in:
+            raise RuntimeError(f"resample: input length {x.shape[-1]} does not match the table ({t_in})")
+        rows = x.numel() // t_in
+        out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
+        call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
+             taps, _stream())
+        ctx.tables = (fwd, bwd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fwd, bwd = ctx.tables
+        return _Gather.apply(g, bwd, fwd), None, None
+
+
+class _Scale(Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.c = c
+        return axpby_raw(x, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Scale.apply(g, ctx.c), None
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, a, b, ca, cb):
+        ctx.c = (ca, cb)
+        return axpby_raw(a, ca, b, cb)
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb = ctx.c
+        ga = _Scale.apply(g, ca) if ctx.needs_input_grad[0] else None
+        gb = _Scale.apply(g, cb) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
+
+
+def axpby(a, ca, b, cb):
+    """ca*a + cb*b (fade-in blends)."""
+    return _Axpby.apply(a, b, float(ca), float(cb))
+
+
+# --------------------------------------------------------------------------------------- minibatch stddev
+class _MbStdBwd(Function):
+    @staticmethod
+    def forward(ctx, x, gout, group):
+        gout = _chk(gout, "mbstd gout")
+        B, Cc, T = x.shape
+        gx = torch.empty_like(x)
+        call("eeggan_mbstd_bwd", x.data_ptr(), gout.data_ptr(), gx.data_ptr(), B, Cc, T, group, _stream())
+        ctx.save_for_backward(x, gout)
+        ctx.group = group
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, q):
+        x, gout = ctx.saved_tensors
+        q = _chk(q, "mbstd cotangent")
+        B, Cc, T = x.shape
+        ggout = torch.empty_like(gout)
+        gx2 = torch.empty_like(x)
+        call("eeggan_mbstd_bwd_bwd", x.data_ptr(), gout.data_ptr(), q.data_ptr(), ggout.data_ptr(), gx2.data_ptr(),
+             B, Cc, T, ctx.group, _stream())
+        return gx2, ggout, None
+
+
+class _MbStd(Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        x = _chk(x, "mbstd x")
+        B, Cc, T = x.shape
+        out = torch.empty((B, Cc + 1, T), device=x.device, dtype=torch.float32)
+        call("eeggan_mbstd_fwd", x.data_ptr(), out.data_ptr(), B, Cc, T, group, _stream())
+        ctx.save_for_backward(x)
+        ctx.group = group
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        return _MbStdBwd.apply(x, gout, ctx.group), None
+
+
+def minibatch_stddev(x, group):
+    return _MbStd.apply(x, int(group))
+
+
+# --------------------------------------------------------------------------------------- losses
+class _WganGpLoss(Function):
+    @staticmethod
+    def forward(ctx, d_real, d_fake, g, drift, lam, target):
+        d_real, d_fake, g = _chk(d_real, "d_real"), _chk(d_fake, "d_fake"), _chk(g, "penalty gradient")
+        B = d_real.numel()
+        per = g.numel() // B
+        norms = torch.empty((B,), device=g.device, dtype=torch.float32)
+        loss = torch.empty((), device=g.device, dtype=torch.float32)
+        call("eeggan_wgan_gp_loss_fwd", d_real.data_ptr(), d_fake.data_ptr(), g.data_ptr(), norms.data_ptr(),
+             loss.data_ptr(), B, per, drift, lam, target, _stream())
+        ctx.save_for_backward(d_real, g, norms)
+        ctx.cfg = (drift, lam, target)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        d_real, g, norms = ctx.saved_tensors
+        drift, lam, target = ctx.cfg
+        gl = _chk(gl, "loss grad")
+        B = d_real.numel()
+        per = g.numel() // B
+        g_r, g_f, g_g = torch.empty_like(d_real), torch.empty_like(d_real), torch.empty_like(g)
+        call("eeggan_wgan_gp_loss_bwd", gl.data_ptr(), d_real.data_ptr(), g.data_ptr(), norms.data_ptr(),
+             g_r.data_ptr(), g_f.data_ptr(), g_g.data_ptr(), B, per, drift, lam, target, _stream())
+        return g_r, g_f, g_g, None, None, None
+
+
+def wgan_gp_d_loss(d_real, d_fake, g, drift, lam, target):
+    """mean(d_fake) - mean(d_real) + drift*mean(d_real^2) + lam/target^2 * mean((|g_b| - target)^2)."""
+    return _WganGpLoss.apply(d_real, d_fake, g, float(drift), float(lam), float(target))
+
+
+class _MeanScale(Function):
+    @staticmethod
+    def forward(ctx, v, scale):
+        v = _chk(v, "mean input")
+        out = torch.empty((), device=v.device, dtype=torch.float32)
+        call("eeggan_mean_scale", v.data_ptr(), out.data_ptr(), v.numel(), scale, _stream())
+        ctx.shape, ctx.scale = v.shape, scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        gl = _chk(gl, "loss grad")
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        out = torch.empty(ctx.shape, device=gl.device, dtype=torch.float32)
+        call("eeggan_mean_scale_bwd", gl.data_ptr(), out.data_ptr(), n, ctx.scale, _stream())
+        return out, None
+
+
+def mean_scale(v, scale):
+    return _MeanScale.apply(v, float(scale))

@@ -1,0 +1,108 @@
+"""The plugin that steers the hot path: ``DepthManager`` (reference plugins.py:28-119) maps the
+number of images shown so far to (depth, alpha) of the progressive schedule and, on a depth
+change, installs the stage's minibatch size, learning rate (256 * lr / minibatch), optimizers,
+data loader and latent generator.  ``Plugin`` is the small base class of the reference's plugin
+protocol (torch_utils.py:4-12).  Monitoring / checkpoint / metric plugins are outside this package.
+"""
+from __future__ import annotations
+
+
+class Plugin(object):
+    def __init__(self, interval=None):
+        if interval is None:
+            interval = []
+        self.trigger_interval = interval
+
+    def register(self, trainer):
+        raise NotImplementedError
+
+
+class DepthManager(Plugin):
+    minibatch_override = {0: 256, 1: 256, 2: 128, 3: 128, 4: 48, 5: 32, 6: 32, 7: 32, 8: 16, 9: 16, 10: 8, 11: 8}
+    tick_kimg_override = {4: 4, 5: 4, 6: 4, 7: 3, 8: 3, 9: 2, 10: 2, 11: 1}
+    training_kimg_override = {1: 200, 2: 200, 3: 200, 4: 200}
+    transition_kimg_override = {1: 200, 2: 200, 3: 200, 4: 200}
+
+    def __init__(self, create_dataloader_fun, create_rlg, max_depth, tick_kimg_default, get_optimizer, default_lr,
+                 reset_optimizer: bool = True, disable_progression=False, minibatch_default=256, depth_offset=0,
+                 lod_training_kimg=400, lod_transition_kimg=400):
+        super().__init__([(1, "iteration")])
+        self.reset_optimizer = reset_optimizer
+        self.minibatch_default = minibatch_default
+        self.tick_kimg_default = tick_kimg_default
+        self.create_dataloader_fun = create_dataloader_fun
+        self.create_rlg = create_rlg
+        self.trainer = None
+        self.depth = -1
+        self.alpha = -1
+        self.get_optimizer = get_optimizer
+        self.disable_progression = disable_progression
+        self.depth_offset = depth_offset
+        self.max_depth = max_depth
+        self.default_lr = default_lr
+        self.alpha_map = self.pre_compute_alpha_map(depth_offset, max_depth, lod_training_kimg,
+                                                    self.training_kimg_override, lod_transition_kimg,
+                                                    self.transition_kimg_override)
+
+    def register(self, trainer):
+        self.trainer = trainer
+        trainer.stats["minibatch_size"] = self.minibatch_default
+        trainer.stats["alpha"] = {"log_name": "alpha", "log_epoch_fields": ["{val:.2f}"], "val": self.alpha}
+        self.iteration(is_resuming=trainer.optimizer_d is not None)
+
+    @staticmethod
+    def pre_compute_alpha_map(start_depth, max_depth, lod_training_kimg, lod_training_kimg_overrides,
+                              lod_transition_kimg, lod_transition_kimg_overrides):
+        """Image counts at which a stage stops being stable (even entries) and at which the
+        following fade-in completes (odd entries)."""
+        boundaries, shown = [], 0
+        for stage in range(start_depth + 1, max_depth + 1):
+            shown += int(lod_training_kimg_overrides.get(stage, lod_training_kimg) * 1000)
+            boundaries.append(shown)
+            shown += int(lod_transition_kimg_overrides.get(stage, lod_transition_kimg) * 1000)
+            boundaries.append(shown)
+        return boundaries
+
+    def calc_progress(self, cur_nimg=None):
+        if cur_nimg is None:
+            cur_nimg = self.trainer.cur_nimg
+        depth, alpha = self.depth_offset, 1.0
+        for i, point in enumerate(self.alpha_map):
+            if cur_nimg == point:
+                break
+            fading_segment = i % 2 == 1
+            if cur_nimg > point:
+                if not fading_segment:
+                    depth += 1
+                continue
+            if fading_segment:
+                start = self.alpha_map[i - 1]
+                alpha = (cur_nimg - start) / (point - start)
+            break
+        depth = min(self.max_depth, depth)
+        if self.disable_progression:
+            depth, alpha = self.max_depth, 1.0
+        return depth, alpha
+
+    def iteration(self, is_resuming=False, *args):
+        depth, alpha = self.calc_progress()
+        tr = self.trainer
+        dataset = tr.dataset
+        if depth != self.depth:
+            tr.discriminator.depth = tr.generator.depth = dataset.model_depth = depth
+            self.depth = depth
+            stage = depth - self.depth_offset
+            minibatch_size = self.minibatch_override.get(stage, self.minibatch_default)
+            if self.reset_optimizer and not is_resuming:
+                tr.optimizer_g, tr.optimizer_d, tr.lr_scheduler_g, tr.lr_scheduler_d = self.get_optimizer(
+                    self.minibatch_default * self.default_lr / minibatch_size)
+            self.data_loader = self.create_dataloader_fun(minibatch_size)
+            tr.dataiter = iter(self.data_loader)
+            tr.random_latents_generator = self.create_rlg(minibatch_size)
+            tr.tick_duration_nimg = int(self.tick_kimg_override.get(stage, self.tick_kimg_default) * 1000)
+            tr.stats["minibatch_size"] = minibatch_size
+        if alpha != self.alpha:
+            tr.discriminator.alpha = tr.generator.alpha = dataset.alpha = alpha
+            self.alpha = alpha
+        tr.stats["depth"] = depth
+        tr.stats["alpha"]["val"] = alpha

@@ -1,0 +1,174 @@
+/*
+ * eeggan_hip.h -- C ABI of libeeggan_hip.so: the MI355X (gfx950) kernels behind the
+ * EEG-GAN progressive 1-D WGAN-GP training step.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless stated otherwise;
+ *     activations are [B, C, T] with T fastest, conv weights [Cout, Cin, K];
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every entry
+ *     point only enqueues work on it: no allocation, no synchronisation, no host copies,
+ *     so a caller may capture any of them into a hipGraph;
+ *   - return value 0 = success, non-zero = error; eeggan_last_error() returns the message
+ *     of the last failure on the calling thread.  Shape/argument errors are detected on
+ *     the host BEFORE anything is launched.
+ *
+ * Each declaration cites the reference operation it replaces (path:line in the
+ * reference repository).
+ */
+#ifndef EEGGAN_HIP_H
+#define EEGGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------------------- */
+const char* eeggan_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int eeggan_abi_version(void);
+
+/* activation codes for the conv epilogue */
+#define EEGGAN_ACT_NONE  0
+#define EEGGAN_ACT_LRELU 1   /* act_param = negative slope (nn.LeakyReLU, layers.py:196-200) */
+#define EEGGAN_ACT_TANH  2   /* act_param = input scale   (ScaledTanh, layers.py:17-23)      */
+#define EEGGAN_ACT_MASK  3   /* v *= (act_aux[b,co,t] > 0 ? 1 : act_param): the LeakyReLU mask of a
+                                saved layer output applied to this conv's OUTPUT (second-order pass) */
+
+/* ---- equalized-lr Conv1d, stride 1, "same" zero padding pad=(K-1)/2, K in {1,3} ------
+ * Replaces EqualizedConv1d.forward (layers.py:173-174) + the epilogue chain of
+ * GeneralConv.forward (layers.py:207-213):
+ *   y[b,co,t] = drop[b,co] * act( bias[co] + sum_{ci,j} w[co,ci,j] * in_scale * x[b,ci,t+j-pad] )
+ * bias and drop may be NULL.
+ * transposed != 0 computes the input-gradient of that convolution instead (the
+ * "conv_transpose" of the pair): `w` is still the FORWARD weight [Cin_fwd=Cout, Cout_fwd=Cin, K]
+ * and  y[b,ci,t] = in_scale * sum_{co,j} w[co,ci,j] * x[b,co,t-j+pad]   (x = grad wrt conv output;
+ * here the argument Cin is the forward Cout and the argument Cout the forward Cin).
+ * In both modes, if mask_y != NULL the input is first multiplied elementwise by
+ *   mask_drop[b,ci] * (mask_y[b,ci,t] > 0 ? 1 : mask_slope)
+ * (mask_drop may be NULL), i.e. the backward of a fused LeakyReLU+GDrop epilogue
+ * (layers.py:26-38,196-204) applied on the fly. */
+int eeggan_conv1d(const float* x, const float* w, const float* bias, const float* drop, float* y,
+                  int B, int Cin, int Cout, int T, int K, float in_scale, int transposed,
+                  int act, float act_param, const float* act_aux,
+                  const float* mask_y, const float* mask_drop, float mask_slope,
+                  void* stream);
+
+/* Weight- and bias-gradient of the same convolution (autograd of nn.Conv1d, layers.py:154-155):
+ *   gw[co,ci,j] = in_scale * sum_{b,t} gy[b,co,t] * x[b,ci,t+j-pad],  gb[co] = sum_{b,t} gy[b,co,t]
+ * gb may be NULL.  If mask_y != NULL, gy is first multiplied by
+ * mask_drop[b,co] * (mask_y[b,co,t] > 0 ? 1 : mask_slope) as above.
+ * `workspace` must hold eeggan_conv1d_wgrad_workspace(...) bytes; the sum over the
+ * partial slabs is done in a fixed order, so results are run-to-run deterministic. */
+size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T, int K);
+int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb,
+                        int B, int Cin, int Cout, int T, int K, float in_scale,
+                        const float* mask_y, const float* mask_drop, float mask_slope,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal (network.py:158-159,302-303) --
+ *   y[b,co,t] = drop[b,co]*act(bias[co] + in_scale * sum_ci w[co,ci,KT-1-t] * z[b,ci]),  t in [0,KT)
+ * wgrad: gw[co,ci,KT-1-t] = in_scale * sum_b gy[b,co,t] * z[b,ci];  gb[co] = sum_{b,t} gy[b,co,t]
+ * dgrad: gz[b,ci] = in_scale * sum_{co,t} w[co,ci,KT-1-t] * gy[b,co,t] */
+int eeggan_head_fwd(const float* z, const float* w, const float* bias, const float* drop, float* y,
+                    int B, int Cin, int Cout, int KT, float in_scale, int act, float act_param,
+                    void* stream);
+int eeggan_head_wgrad(const float* z, const float* gy, float* gw, float* gb,
+                      int B, int Cin, int Cout, int KT, float in_scale, void* stream);
+int eeggan_head_dgrad(const float* gy, const float* w, float* gz,
+                      int B, int Cin, int Cout, int KT, float in_scale, void* stream);
+
+/* ---- D tail: Conv1d(k=KT, pad=0) on a length-KT signal (network.py:416-418) -----------
+ *   y[b,co] = drop[b,co]*act(bias[co] + in_scale * sum_{ci,t} w[co,ci,t] * x[b,ci,t])
+ * dgrad: gx[b,ci,t] = in_scale * sum_co w[co,ci,t] * gy[b,co]
+ * wgrad: gw[co,ci,t] = in_scale * sum_b gy[b,co] * x[b,ci,t];  gb[co] = sum_b gy[b,co]
+ * (B <= 1024 for the weight gradient.) */
+int eeggan_tail_fwd(const float* x, const float* w, const float* bias, const float* drop, float* y,
+                    int B, int Cin, int Cout, int KT, float in_scale, int act, float act_param,
+                    void* stream);
+int eeggan_tail_dgrad(const float* gy, const float* w, float* gx,
+                      int B, int Cin, int Cout, int KT, float in_scale, void* stream);
+int eeggan_tail_wgrad(const float* x, const float* gy, float* gw, float* gb,
+                      int B, int Cin, int Cout, int KT, float in_scale, void* stream);
+
+/* ---- elementwise / normalisation ----------------------------------------------------- */
+/* out = g * drop[b,c] * (y > 0 ? 1 : slope): backward of LeakyReLU (layers.py:200) followed
+ * by GDrop (layers.py:32-38); drop may be NULL.  n = B*C*T, ct = T. */
+int eeggan_lrelu_drop_bwd(const float* g, const float* y, const float* drop, float* out,
+                          int B, int C, int T, float slope, void* stream);
+/* PixelNorm (utils.py:133-136) followed by GDrop:  d[b,t] = rsqrt(mean_c h^2 + eps),
+ * y = h * d * drop[b,c].  drop may be NULL; d (size B*T) is saved for the backward. */
+int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, float* y, float* d,
+                              int B, int C, int T, float eps, void* stream);
+/* Backward of LeakyReLU -> PixelNorm -> GDrop w.r.t. the conv output, from the layer
+ * OUTPUT y: with u = gy*drop, p = y/drop:  gh = d*(u - p*mean_c(u*p)); gc = gh*(y>0?1:slope).
+ * slope = 1 gives the backward of PixelNorm->GDrop alone. */
+int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop, const float* d,
+                              float* gc, int B, int C, int T, float slope, void* stream);
+/* gc = gy * scale * (1 - y^2): backward of y = tanh(scale*c) (layers.py:17-23). */
+int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_t n, float scale, void* stream);
+/* out = ca*a + cb*b (b may be NULL: out = ca*a).  Fade-in blends network.py:393-396,533-540. */
+int eeggan_axpby(const float* a, float ca, const float* b, float cb, float* out, size_t n, void* stream);
+/* out[b,:] = mix[b]*real[b,:] + (1-mix[b])*fake[b,:]  (losses.py:107-108); per = C*T. */
+int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out,
+                     int B, size_t per, void* stream);
+/* out = base ** n elementwise (GDrop multipliers (1+strength)**N(0,1), layers.py:36). */
+int eeggan_pow_base(const float* n, float* out, size_t count, float base, void* stream);
+
+/* ---- rational resampler (utils.py:204-251) --------------------------------------------
+ * out[r, m] = sum_{k<taps} coef[m*taps+k] * x[r, idx[m*taps+k]],  r in [0,rows), m in [0,Tout).
+ * The host builds (idx, coef) for "linear-interpolate x p then average-pool / q" and for its
+ * transpose; both directions use this one gather kernel. */
+int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float* out,
+                    size_t rows, int Tin, int Tout, int taps, void* stream);
+
+/* ---- MinibatchStddev (layers.py:67-90), one temporal window ------------------------------
+ * fwd: out[B, C+1, T]: channels [0,C) = x, channel C = mean_{c,t} sqrt(mean_g (x - mean_g x)^2)
+ *      over the G = min(B, group) interleaved members {m, m+B/G, ...} of sample b's group.
+ * bwd: gx = gout[:, :C] + d(out[:,C])/dx^T gout[:, C]
+ * bwd_bwd: given q = cotangent of gx:  ggout[B, C+1, T] and gx2[B, C, T] (the derivative of
+ *      bwd w.r.t. gout and w.r.t. x). */
+int eeggan_mbstd_fwd(const float* x, float* out, int B, int C, int T, int group, void* stream);
+int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
+                     void* stream);
+int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
+                         int B, int C, int T, int group, void* stream);
+
+/* ---- WGAN-GP loss (losses.py:94-100,114-119 and 47-48) -----------------------------------
+ * loss = mean(d_fake) - mean(d_real) + drift*mean(d_real^2) + lambda/target^2 * mean((|g_b|_2 - target)^2)
+ * g is [B, per]; norms[B] is written for the backward; loss is one float. */
+int eeggan_wgan_gp_loss_fwd(const float* d_real, const float* d_fake, const float* g, float* norms,
+                            float* loss, int B, size_t per, float drift, float lambda, float target,
+                            void* stream);
+/* gl = upstream scalar gradient (device pointer to one float). */
+int eeggan_wgan_gp_loss_bwd(const float* gl, const float* d_real, const float* g, const float* norms,
+                            float* g_d_real, float* g_d_fake, float* g_g,
+                            int B, size_t per, float drift, float lambda, float target, void* stream);
+/* out[0] = scale * mean(v[0..n))  (generator loss -mean(d_fake): scale = -1). */
+int eeggan_mean_scale(const float* v, float* out, int n, float scale, void* stream);
+/* out[i] = gl[0] * scale / n  for i in [0,n): backward of eeggan_mean_scale. */
+int eeggan_mean_scale_bwd(const float* gl, float* out, int n, float scale, void* stream);
+
+/* ---- multi-tensor Adam (torch.optim.Adam built at train.py:131-136, stepped at trainer.py:90,94)
+ * table: DEVICE array of `ntensors` descriptors; sizes_host: HOST array of the same n's (used
+ * only to size the grid); one launch updates every tensor:
+ *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * grad_scale multiplies every gradient first (1/world_size after a summed all-reduce). */
+typedef struct {
+    float* p; const float* g; float* m; float* v; int64_t n;
+} eeggan_adam_tensor;
+int eeggan_adam_step(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors,
+                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                     void* stream);
+/* dst_flat[offset_i + k] = src_i[k] for every tensor of the table (p = dst slice, g = src):
+ * packs gradients into one bucket for a single all-reduce (or unpacks with swapped roles). */
+int eeggan_multi_copy(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEGGAN_HIP_H */

@@ -1,0 +1,451 @@
+"""CPU oracle for the EEG-GAN progressive 1-D WGAN-GP training step.
+
+TEST INFRASTRUCTURE ONLY.  This module is a CPU restatement, in stock PyTorch
+ops, of the arithmetic the reference performs on its hot path.  It exists to
+check the HIP path and to be timed as the CPU baseline.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; nothing in the shipped package may.
+
+Parity status: PINNED.  ``tools/make_golden.py`` imports the reference's own
+modules in the build container, runs them on seeded inputs and checks this
+restatement against them (fp64: to round-off) before writing the fixtures
+under ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks the
+restatement against those fixtures wherever the tests run.
+
+Everything is functional: a network is a flat ``dict`` of tensors keyed by the
+reference's ``state_dict`` names plus a ``dict`` of equalized-lr scales keyed
+by the conv's module path (the reference keeps that scale as a Python float
+outside the state_dict, layers.py:165-169).
+
+Reference lines each function follows are cited in its docstring
+(paths relative to the reference repository root).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-8  # utils.py:14
+
+
+# --------------------------------------------------------------------------- config
+@dataclass
+class NetConfig:
+    """Default-config constants of the path (defaults.yml:16-58, dataset.py:28-51)."""
+    initial_kernel_size: int = 32
+    num_rgb_channels: int = 5
+    fmap_base: int = 1024
+    fmap_max: int = 256
+    fmap_min: int = 64
+    kernel_size: int = 3
+    scale_up: Sequence[int] = (4, 2, 2, 3, 4, 5, 3)
+    scale_down: Sequence[int] = (1, 1, 1, 2, 3, 4, 2)
+    act_alpha: float = 0.2
+    latent_size: int = 256
+    g_dropout: float = 0.2
+    d_dropout: float = 0.2
+    group_size: int = 4
+    tanh_scale: float = 0.5
+
+    def nf(self, stage: int) -> int:
+        """network.py:279-280."""
+        return min(max(int(self.fmap_base / (2.0 ** stage)), self.fmap_min), self.fmap_max)
+
+    @property
+    def num_stages(self) -> int:
+        return len(self.scale_up)
+
+    def seq_len(self, depth: int) -> int:
+        t = self.initial_kernel_size
+        for i in range(depth):
+            t = t * self.scale_up[i] // self.scale_down[i]
+        return t
+
+
+# --------------------------------------------------------------------------- parameter layout
+def conv_shapes_generator(cfg: NetConfig) -> List[Tuple[str, int, int, int]]:
+    """(module path, Cin, Cout, k) of every conv in G, in construction order
+    (network.py:302-312, 158-161, 175-176)."""
+    out = []
+
+    def block(prefix, ch_in, ch_out, first):
+        k0 = cfg.initial_kernel_size if first else cfg.kernel_size
+        out.append((f"{prefix}.convs.0", ch_in, ch_out, k0))
+        out.append((f"{prefix}.convs.1", ch_out, ch_out, cfg.kernel_size))
+        out.append((f"{prefix}.to_rgb.0", ch_out, cfg.num_rgb_channels, 1))
+
+    block("block0", cfg.latent_size, cfg.nf(1), True)
+    for i in range(cfg.num_stages):
+        block(f"blocks.{i}", cfg.nf(i + 1), cfg.nf(i + 2), False)
+    return out
+
+
+def conv_shapes_discriminator(cfg: NetConfig) -> List[Tuple[str, int, int, int]]:
+    """(module path, Cin, Cout, k) of every conv in D, in construction order
+    (network.py:501-525, 405-429): the last block is built first, then blocks
+    R-1..0 which land at list positions 0..R-1, then ``linear``."""
+    out = []
+    R = cfg.num_stages
+    # last block: stored at index R; net.0 is the parameter-less MinibatchStddev
+    out.append((f"blocks.{R}.net.1", cfg.nf(1) + 1, cfg.nf(1), cfg.kernel_size))
+    out.append((f"blocks.{R}.net.2", cfg.nf(1), cfg.nf(0), cfg.initial_kernel_size))
+    out.append((f"blocks.{R}.from_rgb", cfg.num_rgb_channels, cfg.nf(1), 1))
+    for pos, i in enumerate(range(R - 1, -1, -1)):
+        ch_in, ch_out = cfg.nf(i + 2), cfg.nf(i + 1)
+        out.append((f"blocks.{pos}.net.0", ch_in, ch_in, cfg.kernel_size))
+        out.append((f"blocks.{pos}.net.1", ch_in, ch_out, cfg.kernel_size))
+        out.append((f"blocks.{pos}.from_rgb", cfg.num_rgb_channels, ch_in, 1))
+    out.append(("linear", cfg.nf(0), 1, 1))
+    return out
+
+
+def init_params(shapes, act_alpha_of, generator: torch.Generator, dtype=torch.float32):
+    """Unit-RMS equalized init (layers.py:156-169): kaiming-normal with the
+    layer's leaky slope, bias zero, then weight /= RMS(weight) and the RMS is
+    kept as the runtime input scale.  This draws from ``generator`` directly
+    and is NOT stream-compatible with the reference's nn.Conv1d construction
+    (which also consumes draws for the default reset); fixtures therefore carry
+    weights produced by the shipped package's modules, not by this helper.
+    """
+    params: Dict[str, torch.Tensor] = {}
+    scales: Dict[str, float] = {}
+    for path, cin, cout, k in shapes:
+        a = act_alpha_of(path)
+        a = a if a > 0 else 1.0
+        gain = math.sqrt(2.0 / (1.0 + a * a))
+        std = gain / math.sqrt(cin * k)
+        w = torch.randn(cout, cin, k, generator=generator, dtype=torch.float64) * std
+        s = float(torch.sqrt(torch.mean(w * w)))
+        params[f"{path}.conv.conv.weight"] = (w / s).to(dtype)
+        params[f"{path}.conv.conv.bias"] = torch.zeros(cout, dtype=dtype)
+        scales[path] = s
+    return params, scales
+
+
+# --------------------------------------------------------------------------- primitive ops
+def equalized_conv1d(x, w, b, scale: float, pad: int):
+    """layers.py:173-174: the INPUT is multiplied by the scale, then a plain
+    cross-correlation with zero padding and an unscaled bias."""
+    return F.conv1d(x * scale, w, b, padding=pad)
+
+
+def pixel_norm(h):
+    """utils.py:133-136: h * rsqrt(mean over channels of h^2 + 1e-8)."""
+    return h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + EPS)
+
+
+def leaky_relu(x, slope: float):
+    """layers.py:196-200 (nn.LeakyReLU, never in place)."""
+    return F.leaky_relu(x, slope)
+
+
+class DropSource:
+    """Source of the GDrop multipliers (layers.py:32-38).
+
+    The reference draws ``(1+strength) ** np.random.normal(size=[B, C, 1])`` on
+    the host at every call, in execution order, in fp64, then casts to the
+    activation dtype.  ``mode='numpy'`` reproduces that stream from the global
+    numpy RNG; ``mode='list'`` replays recorded multipliers; ``mode='off'``
+    returns None (deterministic).
+    """
+
+    def __init__(self, mode: str = "numpy", recorded: Optional[List[np.ndarray]] = None):
+        self.mode = mode
+        self.recorded = list(recorded) if recorded is not None else []
+        self.cursor = 0
+        self.log: List[np.ndarray] = []
+
+    def draw(self, strength: float, b: int, c: int) -> Optional[np.ndarray]:
+        if self.mode == "off" or not strength:
+            return None
+        if self.mode == "list":
+            r = self.recorded[self.cursor]
+            self.cursor += 1
+            assert r.shape == (b, c, 1), (r.shape, (b, c, 1))
+        else:
+            r = (1.0 + strength) ** np.random.normal(size=[b, c, 1])
+        self.log.append(r)
+        return r
+
+
+def gdrop(x, strength: float, src: DropSource):
+    """layers.py:32-38."""
+    r = src.draw(strength, x.shape[0], x.shape[1])
+    if r is None:
+        return x
+    return x * torch.from_numpy(r).to(x.dtype)
+
+
+def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None, drop=0.0,
+                 src: Optional[DropSource] = None):
+    """layers.py:207-213 for the default options: conv -> LeakyReLU ->
+    (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
+    w = params[f"{path}.conv.conv.weight"]
+    b = params[f"{path}.conv.conv.bias"]
+    k = w.shape[2]
+    pad = (k - 1) // 2 if pad is None else pad
+    h = equalized_conv1d(x, w, b, scales[path], pad)
+    if act_alpha >= 0:
+        h = leaky_relu(h, act_alpha) if act_alpha > 0 else F.relu(h)
+    if norm == "pixel":
+        h = pixel_norm(h)
+    if drop:
+        h = gdrop(h, drop, src)
+    return h
+
+
+def linear_interp_upsample(x, p: int):
+    """F.interpolate(scale_factor=p, mode='linear', align_corners=False)
+    (utils.py:204-205) written out: output j samples the input at
+    src = (j + 0.5) / p - 0.5 clamped below at 0, between floor(src) and
+    min(floor(src) + 1, T - 1)."""
+    T = x.shape[-1]
+    j = torch.arange(T * p, dtype=x.dtype)
+    src = torch.clamp((j + 0.5) / p - 0.5, min=0.0)
+    i0 = torch.floor(src).long()
+    i1 = torch.clamp(i0 + 1, max=T - 1)
+    lam = (src - i0.to(x.dtype))
+    return x[..., i0] * (1.0 - lam) + x[..., i1] * lam
+
+
+def avg_pool_down(x, q: int):
+    """F.avg_pool1d(k=q, stride=q, pad=0, ceil_mode=False,
+    count_include_pad=True) (utils.py:208-209)."""
+    T = x.shape[-1]
+    n = T // q
+    return x[..., : n * q].reshape(*x.shape[:-1], n, q).mean(dim=-1)
+
+
+def resample(x, signal_freq: int, desired_freq: int):
+    """utils.py:221-251 for 3-D torch input: ratio = desired/signal reduced to
+    lowest terms; a length-1 signal is repeated; otherwise linear upsample by
+    the numerator then average-pool by the denominator."""
+    if x.shape[2] == 1:
+        ratio = desired_freq / signal_freq
+        assert ratio == int(ratio)
+        return x.repeat(1, 1, int(ratio))
+    r = Fraction(int(desired_freq), int(signal_freq))
+    if r.numerator != 1:
+        x = linear_interp_upsample(x, r.numerator)
+    if r.denominator != 1:
+        x = avg_pool_down(x, r.denominator)
+    return x
+
+
+def minibatch_stddev(x, group_size: int = 4, window: int = 32):
+    """layers.py:74-90 with temporal_groups_per_window=1: per window of
+    ``window`` time steps, samples are split into ``G=min(B, group_size)``
+    interleaved groups (sample i sits with i + B/G, ...); the per-(member,
+    channel, time) standard deviation over the group (no epsilon) is averaged
+    over channels and time and appended as one extra channel."""
+    B, C, T = x.shape
+    G = min(B, group_size)
+    cols = []
+    for start in range(0, T, window):
+        y = x[..., start:start + window]
+        Tw = y.shape[-1]
+        y = y.reshape(G, B // G, C, Tw)
+        y = y - y.mean(dim=0, keepdim=True)
+        sd = torch.sqrt((y * y).mean(dim=0))          # [B/G, C, Tw]
+        s = sd.mean(dim=(1, 2), keepdim=True)          # [B/G, 1, 1]
+        cols.append(s.repeat(G, 1, Tw))
+    return torch.cat([x, torch.cat(cols, dim=2)], dim=1)
+
+
+# --------------------------------------------------------------------------- networks
+def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfig,
+                      src: Optional[DropSource] = None):
+    """network.py:354-396 (default options: pggan rgb mode, pixel norm,
+    normalize_latents, no conditioning).  Returns x[B, 5, T(depth)]."""
+    src = src or DropSource("off")
+    ls = dict(act_alpha=cfg.act_alpha, norm="pixel", drop=cfg.g_dropout, src=src)
+
+    def gblock(prefix, h, first=False):
+        h = general_conv(h, params, scales, f"{prefix}.convs.0",
+                         pad=cfg.initial_kernel_size - 1 if first else None, **ls)
+        return general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
+
+    def to_rgb(prefix, h):
+        c = general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1)
+        return torch.tanh(c * cfg.tanh_scale)  # layers.py:17-23
+
+    h = pixel_norm(z).unsqueeze(2)
+    h = gblock("block0", h, first=True)
+    if depth == 0:
+        return to_rgb("block0", h)
+    for i in range(depth - 1):
+        h = resample(h, cfg.scale_down[i], cfg.scale_up[i])
+        h = gblock(f"blocks.{i}", h)
+    h = resample(h, cfg.scale_down[depth - 1], cfg.scale_up[depth - 1])
+    ult = to_rgb(f"blocks.{depth - 1}", gblock(f"blocks.{depth - 1}", h))
+    if alpha == 1.0:
+        return ult
+    prev = f"blocks.{depth - 2}" if depth > 1 else "block0"
+    return to_rgb(prev, h) * (1.0 - alpha) + ult * alpha
+
+
+def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetConfig,
+                          src: Optional[DropSource] = None):
+    """network.py:528-560 (default options).  Returns (score[B], h[B, 256, 1])."""
+    src = src or DropSource("off")
+    R = cfg.num_stages
+    ls = dict(act_alpha=cfg.act_alpha, norm=None, drop=cfg.d_dropout, src=src)
+
+    def from_rgb(pos, v):
+        return general_conv(v, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
+
+    def dblock(pos, h):
+        if pos == R:
+            h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
+            h = general_conv(h, params, scales, f"blocks.{R}.net.1", **ls)
+            return general_conv(h, params, scales, f"blocks.{R}.net.2", pad=0, **ls)
+        h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
+        return general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+
+    first = R - depth                      # blocks[-(depth+1)]
+    h = dblock(first, from_rgb(first, x))
+    if depth > 0:
+        up, dn = cfg.scale_up[depth - 1], cfg.scale_down[depth - 1]
+        h = resample(h, up, dn)
+        if alpha < 1.0:
+            low = from_rgb(first + 1, resample(x, up, dn))
+            h = h * alpha + (1.0 - alpha) * low
+    for i in range(depth, 0, -1):
+        h = dblock(R + 1 - i, h)
+        if i > 1:
+            h = resample(h, cfg.scale_up[i - 2], cfg.scale_down[i - 2])
+    o = general_conv(h, params, scales, "linear", act_alpha=-1)
+    return o.mean(dim=2).squeeze(), h
+
+
+# --------------------------------------------------------------------------- losses
+def d_loss_wgan_gp(dp, ds, gp_, gs, real, z, depth, alpha, cfg, mix, src_d, src_g,
+                   drift_eps=1e-3, grad_lambda=10.0, target=1.0):
+    """losses.py:73-120, ``wgan_gp`` branch.  ``mix`` is the per-sample mixing
+    factor [B, 1, 1] (losses.py:13-18).  Call order of the stochastic layers:
+    D(real), G(z) without graph, D(fake), D(x_hat)."""
+    d_real, _ = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
+    with torch.no_grad():
+        fake = generator_forward(gp_, gs, z, depth, alpha, cfg, src_g)
+    d_fake, _ = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
+    loss = d_fake.mean() - d_real.mean() + (d_real ** 2).mean() * drift_eps
+    x_hat = (mix * real.detach() + (1.0 - mix) * fake.detach()).requires_grad_(True)
+    pred, _ = discriminator_forward(dp, ds, x_hat, depth, alpha, cfg, src_d)
+    g = torch.autograd.grad(pred, x_hat, torch.ones_like(pred), create_graph=True,
+                            retain_graph=True)[0].reshape(real.shape[0], -1)
+    pen = g.norm(p=2, dim=1) - target
+    loss = loss + (pen ** 2).mean() * grad_lambda / (target ** 2)
+    return loss, dict(d_real=d_real, d_fake=d_fake, fake=fake, x_hat=x_hat, pred=pred, gp_grad=g)
+
+
+def g_loss_wgan(dp, ds, gp_, gs, z, depth, alpha, cfg, src_d, src_g):
+    """losses.py:40-48,70 for ``wgan*``: -mean(D(G(z)))."""
+    fake = generator_forward(gp_, gs, z, depth, alpha, cfg, src_g)
+    d_fake, _ = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
+    return -d_fake.mean(), dict(fake=fake, d_fake=d_fake)
+
+
+# --------------------------------------------------------------------------- schedule
+MINIBATCH_OVERRIDE = {0: 256, 1: 256, 2: 128, 3: 128, 4: 48, 5: 32, 6: 32, 7: 32}  # plugins.py:29-30
+
+
+def alpha_map(max_depth, training_kimg=400, transition_kimg=400):
+    """plugins.py:66-76 with the class overrides (plugins.py:33-34)."""
+    over = {1: 200, 2: 200, 3: 200, 4: 200}
+    pts, ptr = [], 0
+    for i in range(max_depth):
+        ptr += int(over.get(i + 1, training_kimg) * 1000)
+        pts.append(ptr)
+        ptr += int(over.get(i + 1, transition_kimg) * 1000)
+        pts.append(ptr)
+    return pts
+
+
+def calc_progress(cur_nimg, amap, max_depth):
+    """plugins.py:78-97."""
+    depth, alpha = 0, 1.0
+    for i, point in enumerate(amap):
+        if cur_nimg == point:
+            break
+        if cur_nimg > point and i % 2 == 0:
+            depth += 1
+        if cur_nimg < point and i % 2 == 1:
+            alpha = (cur_nimg - amap[i - 1]) / (point - amap[i - 1])
+            break
+        if cur_nimg < point:
+            break
+    return min(max_depth, depth), alpha
+
+
+# --------------------------------------------------------------------------- full step
+@dataclass
+class OracleTrainer:
+    """One ``Trainer.train()`` (trainer.py:79-96): 5 D iterations, each with
+    fresh reals and latents, then 1 G iteration; Adam(betas=(0, .99), eps=1e-8)
+    (defaults.yml:61-64, train.py:131-136)."""
+    dp: Dict[str, torch.Tensor]
+    ds: Dict[str, float]
+    gp: Dict[str, torch.Tensor]
+    gs: Dict[str, float]
+    cfg: NetConfig
+    depth: int
+    alpha: float = 1.0
+    lr: float = 1e-3
+    d_repeats: int = 5
+    opt_d: Optional[torch.optim.Optimizer] = field(default=None)
+    opt_g: Optional[torch.optim.Optimizer] = field(default=None)
+
+    def __post_init__(self):
+        for p in list(self.dp.values()) + list(self.gp.values()):
+            p.requires_grad_(True)
+        self.opt_d = torch.optim.Adam(list(self.dp.values()), self.lr, betas=(0.0, 0.99), eps=1e-8)
+        self.opt_g = torch.optim.Adam(list(self.gp.values()), self.lr, betas=(0.0, 0.99), eps=1e-8)
+
+    def d_iter(self, real, z, mix, src_d, src_g):
+        self.opt_d.zero_grad(set_to_none=True)
+        loss, _ = d_loss_wgan_gp(self.dp, self.ds, self.gp, self.gs, real, z, self.depth, self.alpha,
+                                 self.cfg, mix, src_d, src_g)
+        grads = torch.autograd.grad(loss, [p for p in self.dp.values()], allow_unused=True)
+        for p, g in zip(self.dp.values(), grads):
+            p.grad = g
+        self.opt_d.step()
+        return loss.detach()
+
+    def g_iter(self, z, src_d, src_g):
+        self.opt_g.zero_grad(set_to_none=True)
+        loss, _ = g_loss_wgan(self.dp, self.ds, self.gp, self.gs, z, self.depth, self.alpha, self.cfg,
+                              src_d, src_g)
+        grads = torch.autograd.grad(loss, [p for p in self.gp.values()], allow_unused=True)
+        for p, g in zip(self.gp.values(), grads):
+            p.grad = g
+        self.opt_g.step()
+        return loss.detach()
+
+    def step(self, reals, zs, mixes, src_d, src_g):
+        """reals/mixes: d_repeats entries; zs: d_repeats + 1 entries."""
+        dl = None
+        for i in range(self.d_repeats):
+            dl = self.d_iter(reals[i], zs[i], mixes[i], src_d, src_g)
+        gl = self.g_iter(zs[self.d_repeats], src_d, src_g)
+        return gl, dl
+
+
+def synthetic_eeg(b: int, channels: int, t: int, rng: np.random.Generator, fs_full=60.0, t_full=1920):
+    """Synthetic EEG-like reals: per channel a sum of 6 sinusoids with
+    f ~ U(1, 30) Hz (sampled at fs = 60 * T / 1920 Hz), random phase, 1/f
+    amplitude, plus N(0, 0.1^2) noise, min-max scaled to [-1, 1] per sample
+    (same normalisation as dataset.py:139-144)."""
+    fs = fs_full * t / t_full
+    n = np.arange(t)[None, None, None, :] / fs
+    f = rng.uniform(1.0, 30.0, size=(b, channels, 6, 1))
+    ph = rng.uniform(0, 2 * np.pi, size=(b, channels, 6, 1))
+    x = (np.sin(2 * np.pi * f * n + ph) / f).sum(axis=2) + rng.normal(0, 0.1, size=(b, channels, t))
+    lo = x.min(axis=(1, 2), keepdims=True)
+    hi = x.max(axis=(1, 2), keepdims=True)
+    return ((x - lo) / (hi - lo) * 2.0 - 1.0).astype(np.float32)

@@ -1,0 +1,49 @@
+"""Shared helpers of the test-suite (the oracle is imported only from tests)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().flatten()
+    b = torch.as_tensor(b).detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def maxabs(a, b):
+    a = torch.as_tensor(a).detach().double().cpu().flatten()
+    b = torch.as_tensor(b).detach().double().cpu().flatten()
+    return float((a - b).abs().max())
+
+
+def scales_of(module):
+    return {name[:-len(".conv")]: m.scale for name, m in module.named_modules()
+            if type(m).__name__ == "EqualizedConv1d"}
+
+
+def oracle_params(module, dtype=torch.float64):
+    params = {k: v.detach().cpu().clone().to(dtype) for k, v in module.state_dict().items()}
+    return params, scales_of(module)
+
+
+def subsample(t, n=512):
+    f = torch.as_tensor(t).detach().flatten()
+    stride = max(1, f.numel() // n)
+    return f[::stride][:n].double().cpu().numpy()
+
+
+def check_weights(fx, g, d):
+    """The fixture stores (sum, sum of squares) of every initial weight of the reference run."""
+    for net, m in (("G", g), ("D", d)):
+        for k, v in m.state_dict().items():
+            v = v.double()
+            got = np.array([float(v.sum()), float((v * v).sum())])
+            np.testing.assert_allclose(got, fx[f"wsum_{net}.{k}"], rtol=1e-12, atol=1e-12,
+                                       err_msg=f"{net}.{k} initial weights differ from the reference's")
