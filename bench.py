@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the EEG-GAN training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; gradients all-reduced over RCCL)
+
+One step = one ``Trainer.train()``: 5 discriminator iterations (WGAN-GP, fresh reals and latents)
++ 1 generator iteration, each with Adam, at the FINAL progression stage (depth 7, T = 1920,
+5 channels), alpha = 1, fp32, 32 samples per GPU (the reference's default minibatch at that
+stage), synthetic EEG-like reals resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  ``value`` counts local-batch training steps per second summed
+over all ranks (weak scaling: the global batch is 32 x N).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DEPTH, ALPHA, BATCH = 7, 1.0, 32
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--drop-mode", default="device", choices=["device", "numpy"],
+                    help="'device': GDrop noise drawn on the GPU (same distribution); "
+                         "'numpy': the reference's host RNG stream")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=DEPTH)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    return ap.parse_args()
+
+
+def make_trainer(dev, depth, alpha, batch, seed, world, rank):
+    from eeggan_amd import config, layers
+    from eeggan_amd.optim import Adam
+    from eeggan_amd.parallel import DataParallelStep
+    from eeggan_amd.trainer import Trainer
+    from oracle.ref_cpu import synthetic_eeg  # input synthesis only (same generator as the CPU leg)
+
+    g, d = config.build_models(config.RANDOM_SEED)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = alpha
+    lr = config.stage_lr(depth)
+    opt_g = Adam(g.parameters(), lr, **config.ADAM)
+    opt_d = Adam(d.parameters(), lr, **config.ADAM)
+    T = config.seq_len(depth)
+    rng = np.random.default_rng(seed + rank)
+    pool = [torch.from_numpy(synthetic_eeg(batch, config.NUM_CHANNELS, T, rng)).to(dev) for _ in range(8)]
+    gen = torch.Generator(device=dev).manual_seed(seed + rank)
+
+    def reals():
+        i = 0
+        while True:
+            yield {"x": pool[i % len(pool)]}
+            i += 1
+
+    def latents():
+        while True:
+            yield {"z": torch.randn(batch, config.LATENT_SIZE, device=dev, generator=gen)}
+
+    class _DS:
+        model_depth, alpha = depth, 1.0
+
+    d_loss, g_loss = config.loss_closures()
+    tr = Trainer(d, g, d_loss, g_loss, _DS(), latents(), 0, opt_g, opt_d)
+    tr.dataiter = reals()
+    tr.grad_sync = DataParallelStep() if world > 1 else None
+    return tr
+
+
+def conv_roofline(dev, batch, T):
+    """Dominant kernel: the 64->64, k=3 same-padded conv at T=1920 (54 % of the step's FLOPs are
+    64-channel k=3 convs).  Average launch duration measured with HIP events on the launch stream."""
+    from eeggan_amd import ops
+    C, K = 64, 3
+    x = torch.randn(batch, C, T, device=dev)
+    w = torch.randn(C, C, K, device=dev)
+    b = torch.randn(C, device=dev)
+    r = torch.rand(batch, C, device=dev) + 0.5
+    for _ in range(5):
+        ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2)
+    n = 50
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(n):
+        ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2)
+    e1.record(st)
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / n
+    flops = 2.0 * batch * C * C * K * T
+    achieved = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "conv_fwd_kernel<K=3,CT=64,NT=4,CK=32> (64->64 ch, k=3, T=1920, fused bias+lrelu+drop)",
+            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(sec * 1e6, 2), "flop_per_launch": flops}
+
+
+def cpu_baseline(depth, alpha, batch, seed):
+    """The CPU restatement (oracle, kind 'port') timed on the host cores: one full step after one
+    warm-up discriminator iteration."""
+    from eeggan_amd import config
+    from oracle import ref_cpu as O
+    g, d = config.build_models(config.RANDOM_SEED)
+    sc = lambda m: {n[:-5]: mod.scale for n, mod in m.named_modules() if type(mod).__name__ == "EqualizedConv1d"}
+    gp = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    dp = {k: v.detach().clone() for k, v in d.state_dict().items()}
+    tr = O.OracleTrainer(dp, sc(d), gp, sc(g), O.NetConfig(), depth, alpha, config.stage_lr(depth))
+    T = config.seq_len(depth)
+    rng = np.random.default_rng(seed)
+    reals = [torch.from_numpy(O.synthetic_eeg(batch, 5, T, rng)) for _ in range(5)]
+    zs = [torch.randn(batch, 256) for _ in range(6)]
+    mixes = [torch.rand(batch, 1, 1) for _ in range(5)]
+    src = O.DropSource("numpy")
+    tr.d_iter(reals[0], zs[0], mixes[0], src, src)  # warm-up
+    t0 = time.perf_counter()
+    tr.step(reals, zs, mixes, src, src)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full step (5 D + 1 G iterations with Adam) after 1 warm-up D iteration, depth {depth}, "
+                      f"B={batch}, fp32, torch CPU ops ({dt:.2f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the training step has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    from eeggan_amd import layers
+    layers.set_drop_mode(args.drop_mode)
+    tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        from eeggan_amd import config
+        T = config.seq_len(args.depth)
+        out = {
+            "metric": "G+D WGAN-GP train steps/sec (whole node) at final stage",
+            "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha=1, 5 D + 1 G iterations "
+                                   f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
+                       "parallelism": f"dp{world}", "drop_noise": args.drop_mode, "step_flop": None},
+        }
+        out["roofline"] = conv_roofline(dev, args.batch, T)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.depth, ALPHA, args.batch, 1373)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

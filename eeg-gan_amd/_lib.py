@@ -9,6 +9,12 @@ import ctypes as C
 import os
 from typing import Optional
 
+# PyTorch ships its own copy of the HIP runtime (soname libamdhip64.so.7).  It must be in the
+# process BEFORE this library is opened, so that the library's dependency on that soname binds to
+# the same runtime instance that owns torch's streams and allocations; loaded in the other order
+# the process ends up with two runtimes and every launch on a torch stream fails.
+import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeeggan_hip.so")
 

@@ -444,9 +444,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            float scale, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= E) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * E + i];
-    out[i] = s * scale;
+    // the slabs are few and this pass is bandwidth-trivial: summing them in double removes the
+    // split count from the rounding error of the result
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += (double)ws[(long long)k * E + i];
+    out[i] = (float)(s * (double)scale);
 }
 
 struct WgradPlan {

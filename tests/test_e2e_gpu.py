@@ -1,0 +1,183 @@
+"""End-to-end parity of the HIP path (networks, losses, gradient penalty, Adam) with the
+reference, on the golden fixtures (`tools/make_golden.py`) and against the CPU oracle.
+
+Bars (fp32): outputs, scores and loss values within 1e-4 relative of the reference's fp64 run.
+Parameter gradients: the reference's own fp32 run differs from its fp64 run by up to ~2e-3 at the
+final stage (mostly the float32 interpolation weights of its resampler, plus LeakyReLU mask flips),
+and that distance is stored per tensor in the fixture as `noise`.  A gradient passes when it lies
+within max(1e-4, 2 x noise) of the reference's fp64 evaluation or of its fp32 evaluation, i.e.
+within twice the reference's own uncertainty of one of the two answers the reference gives.
+Generator gradients are linear in the gradient the discriminator hands back (d loss / d fake),
+whose own reference uncertainty (`g_upstream_noise`, up to 3e-3 at the final stage) is a floor for
+them: sums such as the to_rgb bias gradient cancel heavily and amplify it.  (Where no LeakyReLU
+mask flips between the two fp32 runs the hand-back gradient agrees with the reference's fp32 run
+to ~1e-6; a single differing flip moves it by ~5e-4.)"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_weights, load_fixture, oracle_params, rel, subsample
+
+pytestmark = pytest.mark.gpu
+
+E2E = ["e2e_d0_a1", "e2e_d1_a05", "e2e_d4_a1", "e2e_d7_a1", "e2e_d7_a05"]
+
+
+def _build(dev, depth, alpha, seed):
+    from eeggan_amd import config, layers
+    layers.set_drop_mode("numpy")
+    g, d = config.build_models(seed)
+    return g, d
+
+
+def _check_grads(fx, key, module, floor=1e-4):
+    worst = 0.0
+    if key == "g_grads":
+        floor = max(floor, 2.0 * float(fx["g_upstream_noise"]))
+    for k, p in module.named_parameters():
+        if f"{key}_none.{k}" in fx:
+            assert p.grad is None, f"{key}.{k}: the reference leaves this gradient None at this depth"
+            continue
+        assert p.grad is not None, f"{key}.{k}: missing gradient"
+        tol = max(floor, 2.0 * float(fx[f"{key}_noise.{k}"]))
+        got_sub = subsample(p.grad)
+        e64 = rel(got_sub, fx[f"{key}_sub.{k}"])
+        e32 = rel(got_sub, fx[f"{key}_sub32.{k}"])
+        e = min(e64, e32)
+        worst = max(worst, e / tol)
+        assert e < tol, f"{key}.{k}: differs by {e64:.3e} (fp64 ref) / {e32:.3e} (fp32 ref), tolerance {tol:.3e}"
+        n = float(p.grad.double().norm())
+        assert abs(n - float(fx[f"{key}_norm.{k}"])) <= 2 * tol * float(fx[f"{key}_norm.{k}"]) + 1e-12, f"{key}.{k}: norm"
+    return worst
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_against_reference_fixture(dev, name):
+    from eeggan_amd import losses
+    fx = load_fixture(name)
+    depth, alpha, seed = int(fx["depth"]), float(fx["alpha"]), int(fx["seed"])
+    g, d = _build(dev, depth, alpha, int(fx["model_seed"]))
+    check_weights(fx, g, d)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = alpha
+    real = torch.from_numpy(fx["real"]).to(dev)
+    z = torch.from_numpy(fx["z"]).to(dev)
+    mix = torch.from_numpy(fx["mix"]).to(dev)
+
+    np.random.seed(seed)
+    with torch.no_grad():
+        fake = g({"z": z})[0]["x"]
+        score = d({"x": real})[0]
+    assert fake.shape == fx["ref64_fake"].shape
+    assert rel(fake, fx["ref64_fake"]) < 1e-4
+    assert rel(score, fx["ref64_score_real"]) < 1e-4
+
+    np.random.seed(seed + 1)
+    d_loss = losses.discriminator_loss(d, g, {"x": real}, {"z": z}, "wgan_gp", 1e-3, 10.0, 1.0, mixing=mix)
+    d_loss.backward()
+    assert abs(float(d_loss) - float(fx["ref64_d_loss"])) < 1e-4 * max(1.0, abs(float(fx["ref64_d_loss"])))
+    _check_grads(fx, "d_grads", d)
+
+    np.random.seed(seed + 2)
+    fake = g(z)[0]["x"]
+    (up,) = torch.autograd.grad(ops_mean_neg(d(fake)[0]), fake)
+    tol = max(1e-4, 2.0 * float(fx["g_upstream_noise"]))
+    e64, e32 = rel(subsample(up, 2048), fx["g_upstream_sub"]), rel(subsample(up, 2048), fx["g_upstream_sub32"])
+    assert min(e64, e32) < tol, f"discriminator input gradient: {e64:.3e} (fp64 ref) / {e32:.3e} (fp32 ref)"
+
+    np.random.seed(seed + 2)
+    g_loss = losses.generator_loss(d, g, {"x": real}, {"z": z}, "wgan_gp", False, 0.0)
+    g_loss.backward()
+    assert abs(float(g_loss) - float(fx["ref64_g_loss"])) < 1e-4 * max(1.0, abs(float(fx["ref64_g_loss"])))
+    _check_grads(fx, "g_grads", g)
+
+
+def ops_mean_neg(v):
+    from eeggan_amd import ops
+    return ops.mean_scale(v, -1.0)
+
+
+def test_against_oracle_other_config(dev):
+    """A configuration no fixture holds (depth 3, alpha 0.7, B=8), against the fp64 oracle run here."""
+    from eeggan_amd import config, losses
+    from oracle import ref_cpu as O
+    depth, alpha, B, seed = 3, 0.7, 8, 77
+    g, d = _build(dev, depth, alpha, 5)
+    gp, gs = oracle_params(g)
+    dp, ds = oracle_params(d)
+    for p in list(gp.values()) + list(dp.values()):
+        p.requires_grad_(True)
+    T = config.seq_len(depth)
+    rng = np.random.default_rng(seed)
+    real = torch.from_numpy(O.synthetic_eeg(B, 5, T, rng))
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, 256, generator=gen)
+    mix = torch.rand(B, 1, 1, generator=gen)
+    cfg = O.NetConfig()
+    np.random.seed(seed)
+    src = O.DropSource("numpy")
+    loss_ref, aux = O.d_loss_wgan_gp(dp, ds, gp, gs, real.double(), z.double(), depth, alpha, cfg, mix.double(), src,
+                                     src)
+    grads_ref = torch.autograd.grad(loss_ref, list(dp.values()), allow_unused=True)
+
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = alpha
+    np.random.seed(seed)
+    loss = losses.discriminator_loss(d, g, {"x": real.to(dev)}, {"z": z.to(dev)}, "wgan_gp", 1e-3, 10.0, 1.0,
+                                     mixing=mix.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    for (k, p), gr in zip(d.named_parameters(), grads_ref):
+        if gr is None:
+            assert p.grad is None, k
+        else:
+            assert rel(p.grad, gr) < 2e-3, (k, rel(p.grad, gr))  # fp32 noise floor of these gradients
+
+
+def test_full_step_fixture(dev):
+    """One Trainer.train() (5 D + 1 G iterations with Adam) at depth 0 against the reference's
+    parameter updates."""
+    from eeggan_amd import config, layers, losses
+    from eeggan_amd.optim import Adam
+    from eeggan_amd.trainer import Trainer
+    fx = load_fixture("step_depth0")
+    seed, depth, lr = int(fx["seed"]), int(fx["depth"]), float(fx["lr"])
+    layers.set_drop_mode("numpy")
+    g, d = config.build_models(int(fx["model_seed"]))
+    g0 = {k: v.clone() for k, v in g.state_dict().items()}
+    d0 = {k: v.clone() for k, v in d.state_dict().items()}
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    opt_g = Adam(g.parameters(), lr, betas=(0.0, 0.99), eps=1e-8)
+    opt_d = Adam(d.parameters(), lr, betas=(0.0, 0.99), eps=1e-8)
+    mixes = iter([torch.from_numpy(fx[f"mix{i}"]).to(dev) for i in range(5)])
+    d_loss_fn, g_loss_fn = config.loss_closures()
+    d_losses = []
+
+    def d_loss(dis, gen, real, z):
+        out = d_loss_fn(dis, gen, real, z, mixing=next(mixes))
+        d_losses.append(out)
+        return out
+
+    class _DS:
+        model_depth, alpha = depth, 1.0
+
+    tr = Trainer(d, g, d_loss, g_loss_fn, _DS(), iter([{"z": torch.from_numpy(fx[f"z{i}"])} for i in range(6)]), 0,
+                 opt_g, opt_d)
+    tr.dataiter = iter([{"x": torch.from_numpy(fx[f"real{i}"])} for i in range(5)])
+    np.random.seed(seed)
+    tr.train()
+    got = [float(x) for x in d_losses]
+    np.testing.assert_allclose(got, fx["losses64"][:5], rtol=2e-3, atol=2e-4)
+    for net, m, s0 in (("G", g, g0), ("D", d, d0)):
+        for k, v in m.state_dict().items():
+            ref_norm = float(fx[f"{net}_delta_norm.{k}"])
+            delta = v.double().cpu() - s0[k].double()
+            if ref_norm == 0.0:
+                assert float(delta.norm()) == 0.0, f"{net}.{k} must not move at depth 0"
+                continue
+            tol = max(2e-3, 2.0 * float(fx[f"{net}_delta_noise.{k}"]))
+            e = rel(subsample(delta), fx[f"{net}_delta_sub.{k}"])
+            assert e < tol, f"{net}.{k}: update differs by {e:.3e} (tolerance {tol:.3e})"

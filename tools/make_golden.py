@@ -208,6 +208,10 @@ def run_reference(g, d, depth, alpha, real, z, mix, seed, dtype):
     g_loss.backward()
     out["g_loss"] = g_loss.detach()
     out["g_grads"] = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
+    # the gradient the generator receives from the discriminator in that same iteration
+    np.random.seed(seed + 2)
+    fake = g(z)[0]["x"]
+    (out["g_upstream"],) = torch.autograd.grad(-d(fake)[0].mean(), fake)
     return out
 
 
@@ -279,6 +283,9 @@ def e2e_fixture(out_dir, name, depth, alpha, batch, seed):
         fx[f"ref64_{k}"] = r64[k].numpy()
         fx[f"ref32_{k}"] = r32[k].numpy()
         fx[f"noise_{k}"] = np.array(rel(r32[k], r64[k]))
+    fx["g_upstream_noise"] = np.array(rel(r32["g_upstream"], r64["g_upstream"]))
+    fx["g_upstream_sub"] = subsample(r64["g_upstream"], 2048)
+    fx["g_upstream_sub32"] = subsample(r32["g_upstream"], 2048)
     worst_noise = 0.0
     for gk in ("d_grads", "g_grads"):
         for k, v in r64[gk].items():
@@ -287,13 +294,15 @@ def e2e_fixture(out_dir, name, depth, alpha, batch, seed):
                 continue
             fx[f"{gk}_norm.{k}"] = np.array(float(v.norm()))
             fx[f"{gk}_sub.{k}"] = subsample(v)
+            fx[f"{gk}_sub32.{k}"] = subsample(r32[gk][k])
             n32 = rel(r32[gk][k], v)
             fx[f"{gk}_noise.{k}"] = np.array(n32)
             worst_noise = max(worst_noise, n32)
             fx[f"{gk}_oracle32.{k}"] = np.array(rel(o32[gk][k], v))
     np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **fx)
     print(f"{name}.npz: depth={depth} alpha={alpha} B={batch}  oracle64-vs-ref64 worst {w:.2e}; "
-          f"ref32-vs-ref64 worst grad noise {worst_noise:.2e}")
+          f"ref32-vs-ref64 worst grad noise {worst_noise:.2e}; D input-gradient noise "
+          f"{float(fx['g_upstream_noise']):.2e}")
 
 
 def step_fixture(out_dir, seed=11):
