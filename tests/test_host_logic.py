@@ -1,0 +1,132 @@
+"""Host-side logic of the package that needs no GPU: module construction and state-dict layout,
+the progression scheduler, resampling tables, batch sharding for data parallelism."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as O
+
+
+def test_state_dict_layout_and_parameter_counts():
+    from eeggan_amd import config
+    g, d = config.build_models(1)
+    gk, dk = list(g.state_dict()), list(d.state_dict())
+    assert len(gk) == 48 and len(dk) == 50
+    assert sum(p.numel() for p in g.parameters()) == 2976360
+    assert sum(p.numel() for p in d.parameters()) == 2978497
+    assert gk[0] == "block0.convs.0.conv.conv.weight" and "blocks.6.to_rgb.0.conv.conv.bias" in gk
+    assert "blocks.7.net.1.conv.conv.weight" in dk and "blocks.7.net.2.conv.conv.bias" in dk
+    assert "blocks.0.from_rgb.conv.conv.weight" in dk and dk[-1] == "linear.conv.conv.bias"
+    assert d.state_dict()["blocks.7.net.1.conv.conv.weight"].shape == (256, 257, 3)
+    assert g.state_dict()["block0.convs.0.conv.conv.weight"].shape == (256, 256, 32)
+    assert g.max_depth == 7 and d.max_depth == 7 and g.input_latent_size == 256
+    # unit-RMS weights, zero bias, the RMS kept as the runtime input scale
+    c = g.block0.convs[1].conv
+    assert abs(float((c.conv.weight ** 2).mean()) - 1.0) < 1e-5 and float(c.conv.bias.abs().sum()) == 0.0
+    assert 0.0 < c.scale < 1.0
+    # the oracle's table of conv shapes describes the same networks
+    cfg = O.NetConfig()
+    for shapes, sd in ((O.conv_shapes_generator(cfg), g.state_dict()), (O.conv_shapes_discriminator(cfg), d.state_dict())):
+        assert len(shapes) * 2 == len(sd)
+        for path, cin, cout, k in shapes:
+            assert tuple(sd[f"{path}.conv.conv.weight"].shape) == (cout, cin, k)
+
+
+def test_unsupported_options_raise():
+    from eeggan_amd import config
+    from eeggan_amd.network import Discriminator, Generator
+    kw = config.shared_model_kwargs()
+    with pytest.raises(NotImplementedError):
+        Generator(**{**kw, "residual": True}, z_distribution="normal", **config.GENERATOR_KWARGS)
+    with pytest.raises(NotImplementedError):
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "act_norm": "batch"})
+    with pytest.raises(NotImplementedError):
+        Discriminator(**{**kw, "self_attention_layers": [1]}, **config.DISCRIMINATOR_KWARGS)
+    with pytest.raises(NotImplementedError):
+        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "spectral": True})
+
+
+def test_depth_manager_schedule():
+    from eeggan_amd.plugins import DepthManager
+
+    class _Net:
+        depth, alpha = 0, 1.0
+
+    class _Trainer:
+        def __init__(self):
+            self.cur_nimg, self.stats = 0, {}
+            self.discriminator, self.generator, self.dataset = _Net(), _Net(), _Net()
+            self.optimizer_d = self.optimizer_g = None
+
+    lrs, batches = [], []
+    tr = _Trainer()
+    dm = DepthManager(lambda mb: batches.append(mb) or [None], lambda mb: iter(()), 7, 5.0,
+                      lambda lr: lrs.append(lr) or ("g", "d", None, None), 0.001)
+    assert dm.alpha_map == O.alpha_map(7)
+    dm.register(tr)
+    assert (tr.generator.depth, tr.generator.alpha) == (0, 1.0) and batches == [256] and lrs == [0.001]
+    amap = O.alpha_map(7)
+    for nimg in [0, 1, 199999, 200000, 200001, 300000, 400000, 400001, 1000000, 1700000, 3600000, 3700000, 4000000,
+                 4000001, 5999999, 7000000]:
+        assert dm.calc_progress(nimg) == O.calc_progress(nimg, amap, 7), nimg
+    tr.cur_nimg = 3800000
+    dm.iteration()
+    assert tr.discriminator.depth == 7 and tr.discriminator.alpha == 0.5 and tr.dataset.model_depth == 7
+    assert batches[-1] == 32 and abs(lrs[-1] - 0.008) < 1e-12 and tr.tick_duration_nimg == 3000
+    assert tr.optimizer_g == "g" and tr.stats["minibatch_size"] == 32
+
+
+def test_resample_tables_match_interpolate_then_pool():
+    from eeggan_amd.resample_tables import build_tables
+    up, dn = [4, 2, 2, 3, 4, 5, 3], [1, 1, 1, 2, 3, 4, 2]
+    T = 32
+    for i in range(7):
+        for p, q, t_in in ((up[i], dn[i], T), (dn[i], up[i], T * up[i] // dn[i])):
+            x = torch.randn(2, 3, t_in)
+            y = x
+            if p != 1:
+                y = F.interpolate(y, scale_factor=p, mode="linear", align_corners=False)
+            if q != 1:
+                y = F.avg_pool1d(y, q, q, 0, False, True)
+            (idx, coef, a, b, taps), (tidx, tcoef, c, d, ttaps) = build_tables(t_in, p, q)
+            assert (a, b) == (t_in, y.shape[2]) and (c, d) == (y.shape[2], t_in) and taps <= 16 and ttaps <= 16
+            got = (x.double()[..., idx.astype(np.int64)] * torch.from_numpy(coef).double()).sum(-1)
+            assert float((got - y.double()).norm() / y.double().norm()) < 2e-6
+            # the transposed table is the adjoint: <A x, g> == <x, A^T g>
+            g = torch.randn_like(y)
+            back = (g.double()[..., tidx.astype(np.int64)] * torch.from_numpy(tcoef).double()).sum(-1)
+            lhs, rhs = float((got * g.double()).sum()), float((x.double() * back).sum())
+            assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+        T = T * up[i] // dn[i]
+    (idx, coef, a, b, taps), _ = build_tables(1, 4, 1)
+    assert b == 4 and taps == 1 and coef.tolist() == [[1.0]] * 4
+
+
+def test_shard_batch_keeps_minibatch_stddev_groups():
+    from eeggan_amd.parallel import shard_batch
+    B, world = 32, 2
+    x = torch.randn(B, 6, 32, dtype=torch.float64)
+    full = O.minibatch_stddev(x, 4, 32)[:, -1, 0]  # the statistic every sample sees in the global batch
+    seen = {}
+    for r in range(world):
+        xs = shard_batch(x, r, world)
+        assert xs.shape[0] == B // world
+        stat = O.minibatch_stddev(xs, 4, 32)[:, -1, 0]
+        for row, s in zip(xs, stat):
+            j = int(torch.nonzero((x == row).flatten(1).all(dim=1))[0])
+            seen[j] = float(s)
+    assert sorted(seen) == list(range(B))
+    for j, s in seen.items():
+        assert abs(s - float(full[j])) < 1e-12
+    with pytest.raises(ValueError):
+        shard_batch(torch.zeros(12, 1, 1), 0, 8)
+
+
+def test_adam_descriptor_table_layout():
+    import ctypes
+    from eeggan_amd import optim
+    assert optim.DESC_BYTES == 40  # four pointers + int64, as declared in include/eeggan_hip.h
+    arr = (optim._Desc * 2)()
+    arr[1].n = 7
+    assert bytes(arr)[72:80] == (7).to_bytes(8, "little")

@@ -1,0 +1,87 @@
+"""Pins the CPU oracle against the golden vectors produced by the reference implementation
+(tools/make_golden.py).  fp64: to round-off; fp32: within the reference's own fp32 noise."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_weights, load_fixture, oracle_params, rel, subsample
+from oracle import ref_cpu as O
+
+
+def test_per_op_vectors():
+    fx = load_fixture("per_op")
+    t = lambda k: torch.from_numpy(fx[k])
+    for tag in ("k3", "k1", "head", "tail"):
+        x = t(f"conv_{tag}_x").requires_grad_(True)
+        w = t(f"conv_{tag}_w").requires_grad_(True)
+        b = t(f"conv_{tag}_b").requires_grad_(True)
+        y = O.equalized_conv1d(x, w, b, float(fx[f"conv_{tag}_scale"]), int(fx[f"conv_{tag}_pad"]))
+        assert rel(y, fx[f"conv_{tag}_y"]) < 1e-13
+        gx, gw, gb = torch.autograd.grad(y, [x, w, b], t(f"conv_{tag}_gy"))
+        assert rel(gx, fx[f"conv_{tag}_gx"]) < 1e-13 and rel(gw, fx[f"conv_{tag}_gw"]) < 1e-13
+        assert rel(gb, fx[f"conv_{tag}_gb"]) < 1e-13
+    h = t("pn_h").requires_grad_(True)
+    y = O.pixel_norm(h)
+    assert rel(y, fx["pn_y"]) < 1e-14
+    assert rel(torch.autograd.grad(y, h, t("pn_gy"))[0], fx["pn_gh"]) < 1e-13
+    up, dn = [4, 2, 2, 3, 4, 5, 3], [1, 1, 1, 2, 3, 4, 2]
+    for i in range(7):
+        assert rel(O.resample(t(f"rs_up{i}_x"), dn[i], up[i]), fx[f"rs_up{i}_y"]) < 1e-13
+        assert rel(O.resample(t(f"rs_dn{i}_x"), up[i], dn[i]), fx[f"rs_dn{i}_y"]) < 1e-13
+    assert rel(O.resample(t("rs_rep_x"), 1, 4), fx["rs_rep_y"]) == 0.0
+    x = t("mb_x").requires_grad_(True)
+    gy = t("mb_gy").requires_grad_(True)
+    y = O.minibatch_stddev(x, 4, 32)
+    assert rel(y, fx["mb_y"]) < 1e-14
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    assert rel(gx, fx["mb_gx"]) < 1e-13
+    ggy, gxx = torch.autograd.grad(gx, [gy, x], t("mb_v"))
+    assert rel(ggy, fx["mb_ggy"]) < 1e-12 and rel(gxx, fx["mb_gxx"]) < 1e-12
+    assert rel(torch.tanh(t("tanh_c") * 0.5), fx["tanh_y"]) < 1e-15
+
+
+@pytest.mark.parametrize("name", ["e2e_d0_a1", "e2e_d1_a05", "e2e_d4_a1", "e2e_d7_a05"])
+def test_end_to_end_fp64(name):
+    from eeggan_amd import config
+    fx = load_fixture(name)
+    depth, alpha, seed = int(fx["depth"]), float(fx["alpha"]), int(fx["seed"])
+    g, d = config.build_models(int(fx["model_seed"]))
+    check_weights(fx, g, d)
+    gp, gs = oracle_params(g)
+    dp, ds = oracle_params(d)
+    for p in list(gp.values()) + list(dp.values()):
+        p.requires_grad_(True)
+    real, z, mix = (torch.from_numpy(fx[k]).double() for k in ("real", "z", "mix"))
+    cfg = O.NetConfig()
+    # the seeded weights are reproducible to ~1 ulp across CPU models: outputs agree to ~1e-6
+    tol = 2e-5
+    np.random.seed(seed)
+    src = O.DropSource("numpy")
+    with torch.no_grad():
+        fake = O.generator_forward(gp, gs, z, depth, alpha, cfg, src)
+        score = O.discriminator_forward(dp, ds, real, depth, alpha, cfg, src)[0]
+    assert rel(fake, fx["ref64_fake"]) < tol and rel(score, fx["ref64_score_real"]) < tol
+    np.random.seed(seed + 1)
+    src = O.DropSource("numpy")
+    loss, _ = O.d_loss_wgan_gp(dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+    assert abs(float(loss) - float(fx["ref64_d_loss"])) < tol * max(1.0, abs(float(fx["ref64_d_loss"])))
+    grads = torch.autograd.grad(loss, list(dp.values()), allow_unused=True)
+    for k, gr in zip(dp.keys(), grads):
+        if f"d_grads_none.{k}" in fx:
+            assert gr is None
+        else:
+            floor = max(1e-4, 2 * float(fx[f"d_grads_noise.{k}"]))  # ulp-level weight differences, amplified
+            assert rel(subsample(gr), fx[f"d_grads_sub.{k}"]) < floor, k
+
+
+def test_schedule_matches_reference_description():
+    amap = O.alpha_map(7)
+    assert amap == [200000, 400000, 600000, 800000, 1000000, 1200000, 1400000, 1600000, 2000000, 2400000, 2800000,
+                    3200000, 3600000, 4000000]
+    assert O.calc_progress(0, amap, 7) == (0, 1.0)
+    assert O.calc_progress(300000, amap, 7) == (1, 0.5)
+    assert O.calc_progress(3800000, amap, 7) == (7, 0.5)
+    assert O.calc_progress(5000000, amap, 7) == (7, 1.0)
+    cfg = O.NetConfig()
+    assert [cfg.seq_len(d) for d in range(8)] == [32, 128, 256, 512, 768, 1024, 1280, 1920]
+    assert [cfg.nf(s) for s in range(9)] == [256, 256, 256, 128, 64, 64, 64, 64, 64]
