@@ -33,8 +33,6 @@ struct ConvArgs {
     int B, Cin, Cout, T;
     int ST;  // 32-wide subtiles per sample = ceil(T/32)
     int NS;  // total subtiles = B*ST
-    int wsA, wsB, wsC, wOff;  // weight address = co*wsA + ci*wsB + tap*wsC + wOff
-    int transposed;
     float in_scale;
     int act;
     float act_param;
@@ -146,25 +144,35 @@ struct XStage {
 };
 
 // ---------------------------------------------------------------------------------------
-// Forward / input-gradient kernel.
-//   K   taps (1 or 3);  CT output channels per workgroup;  NT subtiles per workgroup;
-//   CK  input channels per K-chunk;  WM x WN wave grid over (channel tiles x subtiles).
-template <int K, int CT, int NT, int CK, int WM, int WN>
+// Forward kernel (the input gradient is the same kernel on tap-flipped, channel-transposed
+// weights, see eeggan_conv1d_flip_weights).
+//
+// Persistent workgroups walk a flattened list of (tile, Cin-chunk) steps.  A tile is CT output
+// channels x NT 32-wide subtiles; a chunk is CK = 32 input channels.  Per step the weight chunk
+// [CT][CK*K] and the activation chunk [CK][NT*40] are staged global -> registers -> LDS into the
+// buffer the NEXT step reads (two LDS buffers, loads issued before the MFMA block and written
+// after it), so one barrier per step suffices and global latency hides under 48-96 MFMAs.
+//   K taps (1|3);  WM x WN wave grid over (32-channel row tiles x subtiles);  VEC: T % 4 == 0.
+constexpr int CK = 32;
+
+template <int K, int CT, int NT, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
     constexpr int XLD = NT * SUB;
     constexpr int RM = CT / 32 / WM;
     constexpr int RN = NT / WN;
-    constexpr int KH = CK / 2 * K;  // k-steps per chunk (each MFMA consumes 2 reduction indices)
-    constexpr int WE = CT * CK * K;  // weight elements per chunk
-    constexpr int WPT = (WE + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(KH % 4 == 0, "k-steps must group by 4 for b128 reads");
+    constexpr int KH = CK / 2 * K;      // k-steps per chunk (each MFMA consumes 2 reduction indices)
+    constexpr int WQ = CK * K / 4;      // float4 per weight row of a chunk
+    constexpr int WV = CT * WQ / 256;   // float4 weight items per thread
+    constexpr int XV = CK * NT * 8 / 256;  // float4 activation items per thread (= NT)
+    constexpr int XROWS = 32 / NT;      // activation rows covered per pass of the 256 threads
+    constexpr int HROWS = 128 / NT;     // halo rows covered per pass
+    constexpr int HV = (CK + HROWS - 1) / HROWS;
+    constexpr int BUF = CT * WLD + CK * XLD;
+    static_assert(WM * WN == 4 && KH % 4 == 0 && (CT * WQ) % 256 == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;             // [CT][WLD]
-    float* Xs = smem + CT * WLD;  // [CK][XLD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,8 +181,156 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     const int wave = tid >> 6;
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int sub0 = blockIdx.x * NT;
-    const int co0 = blockIdx.y * CT;
+
+    const int tiles_x = (a.NS + NT - 1) / NT;
+    const int tiles_y = (a.Cout + CT - 1) / CT;
+    const int ntiles = tiles_x * tiles_y;
+    const int nchunks = (a.Cin + CK - 1) / CK;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * nchunks;
+    if (nsteps <= 0) return;
+    const bool wvec = ((a.Cin * K) % 4 == 0) && (a.Cin % CK == 0);
+
+    // per-thread staging coordinates that do not depend on the step
+    int w_row[WV], w_q[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int e4 = tid + 256 * i;
+        w_row[i] = e4 / WQ;
+        w_q[i] = e4 - w_row[i] * WQ;
+    }
+    const int x_q = tid & 7, x_n = (tid >> 3) % NT, x_row0 = (tid >> 3) / NT;
+    const int h_side = tid & 1, h_n = (tid >> 1) % NT, h_row0 = (tid >> 1) / NT;
+
+    f32x4 wv[WV], xv[XV];
+    float hv[HV];
+
+    // state of the step being prefetched
+    int p_tile = blockIdx.x, p_chunk = 0;
+    // per-tile staging state (recomputed when the prefetch moves to a new tile)
+    long long x_off = 0, h_off = 0;
+    int x_b = 0, h_b = 0;
+    bool x_ok = false, h_ok = false;
+    int p_co0 = 0;
+
+    auto setup_tile = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        p_co0 = ty * CT;
+        const int sub0 = tx * NT;
+        {
+            const int sub = sub0 + x_n;
+            const int b = sub / a.ST;
+            const int t = (sub - b * a.ST) * 32 + 4 * x_q;
+            x_ok = sub < a.NS && t < a.T;
+            x_b = b;
+            x_off = ((long long)b * a.Cin + x_row0) * a.T + t;
+        }
+        if (K > 1) {
+            const int sub = sub0 + h_n;
+            const int b = sub / a.ST;
+            const int t = (sub - b * a.ST) * 32 + (h_side ? 32 : -1);
+            h_ok = sub < a.NS && t >= 0 && t < a.T;
+            h_b = b;
+            h_off = ((long long)b * a.Cin + h_row0) * a.T + t;
+        }
+    };
+
+    auto prefetch = [&]() {  // global -> registers for step (p_tile, p_chunk)
+        const int ci0 = p_chunk * CK;
+        // weights
+        if (wvec) {
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int co = p_co0 + w_row[i];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (co < a.Cout)
+                    v = *reinterpret_cast<const f32x4*>(a.w + ((long long)co * a.Cin + ci0) * K + 4 * w_q[i]);
+                wv[i] = v;
+            }
+        } else {
+            const int lim = (a.Cin - ci0) * K;  // valid floats of this chunk per weight row
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                const int co = p_co0 + w_row[i];
+                const float* src = a.w + ((long long)co * a.Cin + ci0) * K + 4 * w_q[i];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co < a.Cout && 4 * w_q[i] + e < lim) v[e] = src[e];
+                wv[i] = v;
+            }
+        }
+        // activations (optionally times the backward mask of the producing layer)
+        const long long coff = (long long)ci0 * a.T;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int c = ci0 + x_row0 + i * XROWS;
+            const long long off = x_off + coff + (long long)(i * XROWS) * a.T;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (x_ok && c < a.Cin) {
+                if (VEC) {
+                    v = *reinterpret_cast<const f32x4*>(a.x + off);
+                    if (a.mask_y) {
+                        const f32x4 my = *reinterpret_cast<const f32x4*>(a.mask_y + off);
+                        const float md = a.mask_drop ? a.mask_drop[x_b * a.Cin + c] : 1.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? md : md * a.mask_slope;
+                    }
+                } else {
+                    const int t = (int)((x_off - ((long long)x_b * a.Cin + x_row0) * a.T));
+                    const float md = (a.mask_y && a.mask_drop) ? a.mask_drop[x_b * a.Cin + c] : 1.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (t + e < a.T) {
+                            float u = a.x[off + e];
+                            if (a.mask_y) u *= a.mask_y[off + e] > 0.f ? md : md * a.mask_slope;
+                            v[e] = u;
+                        }
+                    }
+                }
+            }
+            xv[i] = v;
+        }
+        if (K > 1) {
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const int row = h_row0 + i * HROWS;
+                const int c = ci0 + row;
+                float u = 0.f;
+                if (h_ok && row < CK && c < a.Cin) {
+                    const long long off = h_off + coff + (long long)(i * HROWS) * a.T;
+                    u = a.x[off];
+                    if (a.mask_y) {
+                        const float md = a.mask_drop ? a.mask_drop[h_b * a.Cin + c] : 1.f;
+                        u *= a.mask_y[off] > 0.f ? md : md * a.mask_slope;
+                    }
+                }
+                hv[i] = u;
+            }
+        }
+    };
+
+    auto commit = [&](float* buf) {  // registers -> LDS buffer
+        float* Ws = buf;
+        float* Xs = buf + CT * WLD;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            f32x4 v = wv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
+            *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i)
+            *reinterpret_cast<f32x4*>(Xs + (x_row0 + i * XROWS) * XLD + x_n * SUB + 4 + 4 * x_q) = xv[i];
+        if (K > 1) {
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                const int row = h_row0 + i * HROWS;
+                if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = hv[i];
+            }
+        }
+    };
 
     f32x16 acc[RM][RN];
 #pragma unroll
@@ -184,70 +340,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    XStage<CK, NT, XLD, (K > 1)> xs;
-    float wreg[WPT];
-
-    auto load_w = [&](int chunk) {
-        const int ci0 = chunk * CK;
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + 256 * i;
-            int row, cl, j;
-            if (!a.transposed) {  // memory order: [co][ci][tap]
-                row = e / (CK * K);
-                const int rem = e - row * (CK * K);
-                cl = rem / K;
-                j = rem - cl * K;
-            } else {  // memory order of the forward weight: [ci][co][tap]
-                cl = e / (CT * K);
-                const int rem = e - cl * (CT * K);
-                row = rem / K;
-                j = K - 1 - (rem - row * K);
-            }
-            const int co = co0 + row, ci = ci0 + cl;
-            float val = 0.f;
-            if (e < WE && co < a.Cout && ci < a.Cin)
-                val = a.w[(long long)co * a.wsA + (long long)ci * a.wsB + j * a.wsC + a.wOff] * a.in_scale;
-            wreg[i] = val;
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + 256 * i;
-            int row, cl, j;
-            if (!a.transposed) {
-                row = e / (CK * K);
-                const int rem = e - row * (CK * K);
-                cl = rem / K;
-                j = rem - cl * K;
-            } else {
-                cl = e / (CT * K);
-                const int rem = e - cl * (CT * K);
-                row = rem / K;
-                j = K - 1 - (rem - row * K);
-            }
-            if (e < WE) Ws[row * WLD + cl * K + j] = wreg[i];
-        }
-    };
-
-    const int nchunks = (a.Cin + CK - 1) / CK;
-    load_w(0);
-    xs.load(a.x, a.mask_y, a.mask_drop, a.mask_slope, a.Cin, a.T, a.ST, a.NS, sub0, 0, a.vec);
-    store_w();
-    xs.store(Xs);
+    setup_tile(p_tile);
+    prefetch();
+    commit(smem);
     __syncthreads();
 
-    const float* Ap = Ws + (wm * RM * 32 + l31) * WLD + h * KH;
-    const float* Bp = Xs + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
+    int c_tile = blockIdx.x, c_chunk = 0;  // step being computed
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
         if (more) {
-            load_w(chunk + 1);
-            xs.load(a.x, a.mask_y, a.mask_drop, a.mask_slope, a.Cin, a.T, a.ST, a.NS, sub0, (chunk + 1) * CK,
-                    a.vec);
+            if (++p_chunk == nchunks) {
+                p_chunk = 0;
+                p_tile += gridDim.x;
+                setup_tile(p_tile);
+            }
+            prefetch();
         }
+        const float* buf = smem + (step & 1) * BUF;
+        const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
+        const float* Bp = buf + CT * WLD + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
 #pragma unroll
         for (int s4 = 0; s4 < KH / 4; ++s4) {
             f32x4 av[RM];
@@ -268,63 +379,103 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[n], acc[i][n], 0, 0, 0);
             }
         }
-        __syncthreads();
-        if (more) {
-            store_w();
-            xs.store(Xs);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: bias -> activation -> per-(sample, channel) multiplier -> store
+        if (c_chunk + 1 == nchunks) {
+            // epilogue of the finished tile: bias -> activation -> per-(sample, channel) multiplier
+            const int ty = c_tile / tiles_x, tx = c_tile - ty * tiles_x;
+            const int co0 = ty * CT;
 #pragma unroll
-    for (int n = 0; n < RN; ++n) {
-        const int sub = sub0 + wn * RN + n;
-        if (sub >= a.NS) continue;
-        const int b = sub / a.ST;
-        const int t = (sub - b * a.ST) * 32 + l31;
-        if (t >= a.T) continue;
+            for (int n = 0; n < RN; ++n) {
+                const int sub = tx * NT + wn * RN + n;
+                const int b = sub / a.ST;
+                const int t = (sub - b * a.ST) * 32 + l31;
+                const bool ok = sub < a.NS && t < a.T;
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
+                for (int i = 0; i < RM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < a.Cout) {
-                    float v = acc[i][n][r];
-                    const long long o = ((long long)b * a.Cout + co) * a.T + t;
-                    if (a.bias) v += a.bias[co];
-                    if (a.act == EEGGAN_ACT_LRELU)
-                        v = v > 0.f ? v : v * a.act_param;
-                    else if (a.act == EEGGAN_ACT_TANH)
-                        v = tanhf(v * a.act_param);
-                    else if (a.act == EEGGAN_ACT_MASK)
-                        v = a.act_aux[o] > 0.f ? v : v * a.act_param;
-                    if (a.drop) v *= a.drop[b * a.Cout + co];
-                    a.y[o] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (ok && co < a.Cout) {
+                            float v = acc[i][n][r];
+                            const long long o = ((long long)b * a.Cout + co) * a.T + t;
+                            if (a.bias) v += a.bias[co];
+                            if (a.act == EEGGAN_ACT_LRELU)
+                                v = v > 0.f ? v : v * a.act_param;
+                            else if (a.act == EEGGAN_ACT_TANH)
+                                v = tanhf(v * a.act_param);
+                            else if (a.act == EEGGAN_ACT_MASK)
+                                v = a.act_aux[o] > 0.f ? v : v * a.act_param;
+                            if (a.drop) v *= a.drop[b * a.Cout + co];
+                            a.y[o] = v;
+                        }
+                        acc[i][n][r] = 0.f;
+                    }
                 }
             }
+            c_chunk = 0;
+            c_tile += gridDim.x;
+        } else {
+            ++c_chunk;
         }
+        if (more) commit(smem + ((step + 1) & 1) * BUF);
+        __syncthreads();
     }
 }
 
-template <int K, int CT, int NT, int CK, int WM, int WN>
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+template <int K, int CT, int NT, int WM, int WN, bool VEC>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(CT * (CK * K + 4) + CK * NT * SUB) * sizeof(float);
-    dim3 grid((a.NS + NT - 1) / NT, (a.Cout + CT - 1) / CT);
-    hipLaunchKernelGGL((conv_fwd_kernel<K, CT, NT, CK, WM, WN>), grid, dim3(256), lds, st, a);
+    constexpr size_t lds = (size_t)2 * (CT * (CK * K + 4) + CK * NT * SUB) * sizeof(float);
+    static bool configured = false;  // opt in to more than 64 KiB of dynamic LDS, once per kernel
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, CT, NT, WM, WN, VEC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("conv1d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return 1;
+        }
+        configured = true;
+    }
+    const long long ntiles = (long long)((a.NS + NT - 1) / NT) * ((a.Cout + CT - 1) / CT);
+    const long long per_cu = lds <= 80 * 1024 ? 2 : 1;
+    long long grid = (long long)num_cus() * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((conv_fwd_kernel<K, CT, NT, WM, WN, VEC>), dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("conv1d");
 }
 
+// Tile choice: the largest tile that still gives every CU a workgroup; the small layers of the
+// path (T = 32 .. 256 at 128-256 channels) otherwise leave most of the chip idle.
 template <int K>
 int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
-    if (a.Cin <= 16) {
-        if (a.Cout <= 32) return launch_fwd<K, 32, 8, 16, 1, 4>(a, st);
-        if (a.Cout <= 64) return launch_fwd<K, 64, 4, 16, 1, 4>(a, st);
-        return launch_fwd<K, 128, 4, 16, 2, 2>(a, st);
-    }
-    if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4>(a, st);
-    if (a.Cout <= 64) return launch_fwd<K, 64, 4, 32, 1, 4>(a, st);
-    return launch_fwd<K, 128, 4, 16, 2, 2>(a, st);  // 37 KB of LDS: two workgroups per CU
+    const long long ns = a.NS;
+    auto tiles = [&](int ct, int nt) { return ((ns + nt - 1) / nt) * ((a.Cout + ct - 1) / ct); };
+    if (!a.vec) return launch_fwd<K, 64, 2, 2, 2, false>(a, st);
+    if (a.Cout <= 32) return launch_fwd<K, 32, 8, 1, 4, true>(a, st);
+    if (tiles(64, 4) >= num_cus()) return launch_fwd<K, 64, 4, 1, 4, true>(a, st);
+    return launch_fwd<K, 64, 2, 2, 2, true>(a, st);
+}
+
+__global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                           int Cin, int K) {
+    const long long n = (long long)Cout * Cin * K;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // i indexes wt[ci][co][j]
+    const int j = (int)(i % K);
+    const long long r = i / K;
+    const int co = (int)(r % Cout);
+    const int ci = (int)(r / Cout);
+    wt[i] = w[((long long)co * Cin + ci) * K + (K - 1 - j)];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -440,15 +591,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
+// independent loads in flight per thread, double accumulation (the split count then does not
+// enter the rounding error), fixed order => run-to-run deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, long long E,
                                                            float scale, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= E) return;
-    // the slabs are few and this pass is bandwidth-trivial: summing them in double removes the
-    // split count from the rounding error of the result
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += (double)ws[(long long)k * E + i];
-    out[i] = (float)(s * (double)scale);
+    __shared__ double part[4][64];
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + el;
+    double acc = 0.0;
+    if (i < E) {
+        int k = sg;
+        for (; k + 28 < nsplit; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(long long)(k + 4 * u) * E + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; k < nsplit; k += 4) acc += (double)ws[(long long)k * E + i];
+    }
+    part[sg][el] = acc;
+    __syncthreads();
+    if (sg == 0 && i < E) out[i] = (float)(((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) * (double)scale);
 }
 
 struct WgradPlan {
@@ -463,7 +628,7 @@ WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K) {
     p.regions = p.nco * p.nci;
     const int ST = (T + 31) / 32;
     const int pairs = (B * ST + 1) / 2;
-    int want = (512 + p.regions - 1) / p.regions;  // ~2 workgroups per CU over the whole grid
+    int want = (256 + p.regions - 1) / p.regions;  // ~1 workgroup per CU over the whole grid
     if (want > pairs) want = pairs;
     if (want < 1) want = 1;
     p.iters = (pairs + want - 1) / want;
@@ -488,29 +653,34 @@ int check_common(int B, int Cin, int Cout, int T, int K) {
 using namespace eeggan;
 
 extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, const float* drop, float* y, int B,
-                             int Cin, int Cout, int T, int K, float in_scale, int transposed, int act,
-                             float act_param, const float* act_aux, const float* mask_y, const float* mask_drop,
-                             float mask_slope, void* stream) {
+                             int Cin, int Cout, int T, int K, float in_scale, int act, float act_param,
+                             const float* act_aux, const float* mask_y, const float* mask_drop, float mask_slope,
+                             void* stream) {
     if (check_common(B, Cin, Cout, T, K)) return 1;
     EEGGAN_REQUIRE(x && w && y, "conv1d: null x/w/y pointer");
     EEGGAN_REQUIRE(act >= 0 && act <= 3, "conv1d: unknown activation code %d", act);
     EEGGAN_REQUIRE(act != EEGGAN_ACT_MASK || act_aux, "conv1d: EEGGAN_ACT_MASK needs act_aux");
+    EEGGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                       (!mask_y || (reinterpret_cast<uintptr_t>(mask_y) & 15) == 0),
+                   "conv1d: x, w and mask_y must be 16-byte aligned");
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.drop = drop; a.y = y;
     a.mask_y = mask_y; a.mask_drop = mask_y ? mask_drop : nullptr; a.mask_slope = mask_slope;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
     a.ST = (T + 31) / 32;
     a.NS = B * a.ST;
-    a.transposed = transposed ? 1 : 0;
-    if (!transposed) {
-        a.wsA = Cin * K; a.wsB = K; a.wsC = 1; a.wOff = 0;
-    } else {  // forward weight is [Cin_arg][Cout_arg][K]; taps flipped
-        a.wsA = K; a.wsB = Cout * K; a.wsC = -1; a.wOff = K - 1;
-    }
     a.in_scale = in_scale; a.act = act; a.act_param = act_param; a.act_aux = act_aux;
     a.vec = (T % 4 == 0) ? 1 : 0;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
+}
+
+extern "C" int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, void* stream) {
+    EEGGAN_REQUIRE(w && wt && Cout > 0 && Cin > 0 && K > 0, "conv1d_flip_weights: bad argument");
+    const long long n = (long long)Cout * Cin * K;
+    hipLaunchKernelGGL(flip_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, wt,
+                       Cout, Cin, K);
+    return check_launch("conv1d_flip_weights");
 }
 
 extern "C" size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T, int K) {
@@ -544,11 +714,11 @@ extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, f
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
     if (check_launch("conv1d_wgrad")) return 1;
     const long long E = (long long)p.slab_elems;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a.ws, p.nsplit, E,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, a.ws, p.nsplit, E,
                        in_scale, gw);
     if (check_launch("conv1d_wgrad reduce")) return 1;
     if (gb) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 255) / 256)), dim3(256), 0, st, a.ws_b,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, a.ws_b,
                            p.nsplit, (long long)Cout, 1.0f, gb);
         if (check_launch("conv1d_wgrad bias reduce")) return 1;
     }

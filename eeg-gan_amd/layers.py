@@ -137,6 +137,7 @@ class EqualizedConv1d(nn.Module):
             w.copy_(w / self.scale)
         self.kernel_size = kernel_size
         self.padding = padding
+        self._flip = ops.FlipCache(self.conv.weight)
 
     def kind(self, x):
         k, pad = self.kernel_size, self.padding
@@ -151,7 +152,7 @@ class EqualizedConv1d(nn.Module):
     def forward(self, x):
         if self.kind(x) != "same":
             raise NotImplementedError("a bare full-length conv is only available fused inside GeneralConv")
-        return ops.conv1d(x, self.conv.weight, self.conv.bias, None, self.scale, ACT_NONE)
+        return ops.conv1d(x, self.conv.weight, self.conv.bias, None, self.scale, ACT_NONE, flip=self._flip)
 
 
 class GeneralConv(nn.Module):
@@ -199,18 +200,18 @@ class GeneralConv(nn.Module):
         if _tanh_scale is not None:  # to_rgb: linear conv + tanh(scale * .)
             if self.act_alpha >= 0 or self.act_norm is not None or self.drop is not None or kind != "same":
                 raise NotImplementedError("fused tanh epilogue needs a plain linear conv")
-            return ops.g_layer(x, w, b, None, s, 0.0, mode="tanh", kind="same", tanh_scale=_tanh_scale)
+            return ops.g_layer(x, w, b, None, s, 0.0, mode="tanh", kind="same", tanh_scale=_tanh_scale, flip=c._flip)
         if self.act_norm == "pixel":
             if self.act_alpha < 0 or kind == "tail":
                 raise NotImplementedError("pixel norm is fused with a (leaky-)ReLU same/head conv only")
             xin = x.squeeze(2) if kind == "head" else x
-            return ops.g_layer(xin, w, b, self._multipliers(x), s, slope, mode="pn", kind=kind)
+            return ops.g_layer(xin, w, b, self._multipliers(x), s, slope, mode="pn", kind=kind, flip=c._flip)
         if self.act_alpha < 0:
             if self.drop is not None or kind != "same":
                 raise NotImplementedError("linear conv with drop / full-length kernel is not supported")
-            return ops.conv1d(x, w, b, None, s, ACT_NONE)
+            return ops.conv1d(x, w, b, None, s, ACT_NONE, flip=c._flip)
         if kind == "same":
-            return ops.conv1d(x, w, b, self._multipliers(x), s, ACT_LRELU, slope)
+            return ops.conv1d(x, w, b, self._multipliers(x), s, ACT_LRELU, slope, flip=c._flip)
         if kind == "tail":
             return ops.tail_conv(x, w, b, self._multipliers(x), s, slope)
         raise NotImplementedError("the length-1 (head) conv is only supported with pixel norm")

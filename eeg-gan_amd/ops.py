@@ -58,8 +58,51 @@ def _p(t: Optional[torch.Tensor]):
 
 
 # --------------------------------------------------------------------------------------- raw kernels
+# Input gradients run the forward kernel on wt[ci, co, j] = w[co, ci, K-1-j].  A layer keeps that
+# view in a FlipCache next to its parameter and rebuilds it only when the weight changes: torch's
+# version counter catches in-place torch updates, the epoch catches updates made by this package's
+# own optimizer kernel, the data pointer catches a parameter moved to other storage.
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _flip_into(w, wt):
+    cout, cin, k = w.shape
+    call("eeggan_conv1d_flip_weights", w.data_ptr(), wt.data_ptr(), cout, cin, k, _stream())
+    return wt
+
+
+class FlipCache:
+    def __init__(self, param):
+        self.param = param
+        self.tag = None
+        self.wt = None
+
+    def get(self):
+        p = self.param
+        tag = (p.data_ptr(), p._version, _weights_epoch)
+        if tag != self.tag:
+            cout, cin, k = p.shape
+            if self.wt is None or self.wt.device != p.device:
+                self.wt = torch.empty((cin, cout, k), device=p.device, dtype=torch.float32)
+            _flip_into(p.detach(), self.wt)
+            self.tag = tag
+        return self.wt
+
+
+def flipped_weights(w, cache=None):
+    if cache is not None:
+        return cache.get()
+    cout, cin, k = w.shape
+    return _flip_into(w, torch.empty((cin, cout, k), device=w.device, dtype=torch.float32))
+
+
 def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, act=ACT_NONE, act_param=0.0,
-               act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0):
+               act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0, flip=None):
     x = _chk(x, "conv1d x")
     w = _chk(w, "conv1d w")
     B, Cin, T = x.shape
@@ -67,11 +110,10 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
     if transposed:
         if w.shape[0] != Cin:
             raise RuntimeError(f"conv1d(transposed): weight {tuple(w.shape)} does not match input channels {Cin}")
-        Cout = w.shape[1]
-    else:
-        if w.shape[1] != Cin:
-            raise RuntimeError(f"conv1d: weight {tuple(w.shape)} does not match input channels {Cin}")
-        Cout = w.shape[0]
+        w = flipped_weights(w.detach(), flip)
+    elif w.shape[1] != Cin:
+        raise RuntimeError(f"conv1d: weight {tuple(w.shape)} does not match input channels {Cin}")
+    Cout = w.shape[0]
     for name, t, shape in (("bias", bias, (Cout,)), ("drop", drop, (B, Cout)), ("act_aux", act_aux, (B, Cout, T)),
                            ("mask_y", mask_y, (B, Cin, T)), ("mask_drop", mask_drop, (B, Cin))):
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32
@@ -80,8 +122,8 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
                                f"got {tuple(t.shape)}")
     y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
     call("eeggan_conv1d", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, T, K,
-         float(in_scale), int(bool(transposed)), int(act), float(act_param), _p(act_aux), _p(mask_y), _p(mask_drop),
-         float(mask_slope), _stream())
+         float(in_scale), int(act), float(act_param), _p(act_aux), _p(mask_y), _p(mask_drop), float(mask_slope),
+         _stream())
     return y
 
 
@@ -185,9 +227,9 @@ class _ConvT(Function):
     itself differentiable w.r.t. gy and w (the double-backward of the gradient penalty)."""
 
     @staticmethod
-    def forward(ctx, gy, w, mask_y, mask_drop, in_scale, slope):
+    def forward(ctx, gy, w, mask_y, mask_drop, in_scale, slope, flip=None):
         gx = conv1d_raw(gy, w, None, None, in_scale=in_scale, transposed=True, mask_y=mask_y, mask_drop=mask_drop,
-                        mask_slope=slope)
+                        mask_slope=slope, flip=flip)
         ctx.save_for_backward(gy, w, mask_y, mask_drop)
         ctx.in_scale, ctx.slope = in_scale, slope
         return gx
@@ -207,14 +249,15 @@ class _ConvT(Function):
         if ctx.needs_input_grad[1] and not _input_grad_only:
             g_w, _ = conv1d_wgrad_raw(q, gy, w.shape[2], in_scale=ctx.in_scale, need_bias=False, mask_y=mask_y,
                                       mask_drop=mask_drop, mask_slope=ctx.slope)
-        return g_gy, g_w, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None
 
 
 class _Conv(Function):
     """y = drop * act(bias + conv(in_scale * x, w)), act in {none, leaky-relu}; twice differentiable."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, drop, in_scale, act, slope):
+    def forward(ctx, x, w, bias, drop, in_scale, act, slope, flip=None):
+        ctx.flip = flip
         if act not in (ACT_NONE, ACT_LRELU):
             raise ValueError("_Conv supports linear and leaky-relu epilogues")
         if act == ACT_NONE and drop is not None:
@@ -230,15 +273,15 @@ class _Conv(Function):
         gy = _chk(gy, "conv grad")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _ConvT.apply(gy, w, y, drop, ctx.in_scale, ctx.slope)
+            gx = _ConvT.apply(gy, w, y, drop, ctx.in_scale, ctx.slope, ctx.flip)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
             gw, gb = _WGrad.apply(x, gy, w.shape[2], ctx.in_scale, ctx.has_bias, y, drop, ctx.slope)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv1d(x, w, bias, drop, in_scale, act, slope=0.0):
+def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None):
     """Fused equalized conv layer of the discriminator path (twice differentiable)."""
-    return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope))
+    return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip)
 
 
 # --------------------------------------------------------------------------------------- D tail
@@ -356,7 +399,8 @@ class _GLayer(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, bias, drop, in_scale, slope, mode, kind, tanh_scale):
+    def forward(ctx, x, w, bias, drop, in_scale, slope, mode, kind, tanh_scale, flip=None):
+        ctx.flip = flip
         x = _chk(x, "G layer x")
         d = None
         if kind == "head":
@@ -405,14 +449,14 @@ class _GLayer(Function):
                      float(in_scale), _stream())
         else:
             if ctx.needs_input_grad[0]:
-                gx = conv1d_raw(gc, w, None, None, in_scale=in_scale, transposed=True)
+                gx = conv1d_raw(gc, w, None, None, in_scale=in_scale, transposed=True, flip=ctx.flip)
             if need_w:
                 gw, gb = conv1d_wgrad_raw(x, gc, w.shape[2], in_scale=in_scale, need_bias=has_bias)
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
-def g_layer(x, w, bias, drop, in_scale, slope, mode="pn", kind="same", tanh_scale=0.5):
-    return _GLayer.apply(x, w, bias, drop, float(in_scale), float(slope), mode, kind, float(tanh_scale))
+def g_layer(x, w, bias, drop, in_scale, slope, mode="pn", kind="same", tanh_scale=0.5, flip=None):
+    return _GLayer.apply(x, w, bias, drop, float(in_scale), float(slope), mode, kind, float(tanh_scale), flip)
 
 
 class _PixelNorm(Function):

@@ -78,6 +78,8 @@ class Adam(torch.optim.Optimizer):
         call("eeggan_adam_step", table.data_ptr(), sizes.ctypes.data, len(rows), float(group["lr"]), float(b1),
              float(b2), float(group["eps"]), int(step_no), float(self.grad_scale),
              torch.cuda.current_stream().cuda_stream)
+        from . import ops
+        ops.bump_weights_epoch()  # cached derived weight views are stale from here on
         # the table and the gradient tensors are referenced by the enqueued kernel: torch's
         # stream-ordered allocator keeps their memory valid until the kernel has run.
         del table, keep

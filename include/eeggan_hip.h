@@ -41,20 +41,21 @@ int eeggan_abi_version(void);
  * Replaces EqualizedConv1d.forward (layers.py:173-174) + the epilogue chain of
  * GeneralConv.forward (layers.py:207-213):
  *   y[b,co,t] = drop[b,co] * act( bias[co] + sum_{ci,j} w[co,ci,j] * in_scale * x[b,ci,t+j-pad] )
- * bias and drop may be NULL.
- * transposed != 0 computes the input-gradient of that convolution instead (the
- * "conv_transpose" of the pair): `w` is still the FORWARD weight [Cin_fwd=Cout, Cout_fwd=Cin, K]
- * and  y[b,ci,t] = in_scale * sum_{co,j} w[co,ci,j] * x[b,co,t-j+pad]   (x = grad wrt conv output;
- * here the argument Cin is the forward Cout and the argument Cout the forward Cin).
- * In both modes, if mask_y != NULL the input is first multiplied elementwise by
+ * bias and drop may be NULL.  x, w (and mask_y) must be 16-byte aligned.
+ * If mask_y != NULL the input is first multiplied elementwise by
  *   mask_drop[b,ci] * (mask_y[b,ci,t] > 0 ? 1 : mask_slope)
  * (mask_drop may be NULL), i.e. the backward of a fused LeakyReLU+GDrop epilogue
- * (layers.py:26-38,196-204) applied on the fly. */
+ * (layers.py:26-38,196-204) applied on the fly.
+ * The INPUT GRADIENT of this convolution (autograd of nn.Conv1d, layers.py:154-155) is the same
+ * entry point called with gy as x and the weight view wt[ci,co,j] = w[co,ci,K-1-j] produced by
+ * eeggan_conv1d_flip_weights (valid until w changes):
+ *   gx[b,ci,t] = in_scale * sum_{co,j} w[co,ci,j] * gy[b,co,t-j+pad]. */
 int eeggan_conv1d(const float* x, const float* w, const float* bias, const float* drop, float* y,
-                  int B, int Cin, int Cout, int T, int K, float in_scale, int transposed,
+                  int B, int Cin, int Cout, int T, int K, float in_scale,
                   int act, float act_param, const float* act_aux,
                   const float* mask_y, const float* mask_drop, float mask_slope,
                   void* stream);
+int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, void* stream);
 
 /* Weight- and bias-gradient of the same convolution (autograd of nn.Conv1d, layers.py:154-155):
  *   gw[co,ci,j] = in_scale * sum_{b,t} gy[b,co,t] * x[b,ci,t+j-pad],  gb[co] = sum_{b,t} gy[b,co,t]

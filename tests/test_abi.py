@@ -34,7 +34,7 @@ def test_abi_version_and_error_channel():
     assert lib.eeggan_abi_version() == 1
     assert isinstance(lib.eeggan_last_error(), bytes)
     # argument validation happens on the host before any launch: safe without a GPU
-    rc = lib.eeggan_conv1d(None, None, None, None, None, 1, 1, 1, 1, 5, 1.0, 0, 0, 0.0, None, None, None, 0.0, None)
+    rc = lib.eeggan_conv1d(None, None, None, None, None, 1, 1, 1, 1, 5, 1.0, 0, 0.0, None, None, None, 0.0, None)
     assert rc != 0 and b"kernel size" in lib.eeggan_last_error()
     assert lib.eeggan_conv1d_wgrad_workspace(32, 64, 64, 1920, 3) > 0
     assert lib.eeggan_conv1d_wgrad_workspace(32, 64, 64, 1920, 5) == 0

@@ -208,6 +208,33 @@ def run_reference(g, d, depth, alpha, real, z, mix, seed, dtype):
     g_loss.backward()
     out["g_loss"] = g_loss.detach()
     out["g_grads"] = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
+    # the three terms of the discriminator loss differentiated separately (same call order, hence
+    # same noise draws, as losses.discriminator_loss): their sum cancels heavily at initialisation
+    # (d mean(D(fake)) and d mean(D(real)) nearly coincide), which makes the TOTAL gradient
+    # ill-conditioned while each term is not.
+    np.random.seed(seed + 1)
+    d.zero_grad()
+    d_real = d(real)[0]
+    with torch.no_grad():
+        fake_ng = g(z)[0]["x"]
+    d_fake = d(fake_ng)[0]
+    x_hat = (mix * real + (1.0 - mix) * fake_ng).requires_grad_(True)
+    pred = d(x_hat)[0]
+    gg = ref_losses.calc_grad(x_hat, pred).view(real.size(0), -1)
+    terms = {"real": -d_real.mean() + (d_real ** 2).mean() * 1e-3, "fake": d_fake.mean(),
+             "gp": ((gg.norm(p=2, dim=1) - 1.0) ** 2).mean() * 10.0}
+    params = dict(d.named_parameters())
+    out["d_terms"] = {}
+    total = {k: None for k in params}
+    for name, val in terms.items():
+        grads = torch.autograd.grad(val, list(params.values()), retain_graph=True, allow_unused=True)
+        out["d_terms"][name] = dict(zip(params.keys(), grads))
+        for k, gr in zip(params.keys(), grads):
+            if gr is not None:
+                total[k] = gr if total[k] is None else total[k] + gr
+    for k, v in out["d_grads"].items():
+        if v is not None:
+            assert rel(total[k], v) < (1e-9 if dtype == torch.float64 else 1e-3), (k, rel(total[k], v))
     # the gradient the generator receives from the discriminator in that same iteration
     np.random.seed(seed + 2)
     fake = g(z)[0]["x"]
@@ -286,6 +313,14 @@ def e2e_fixture(out_dir, name, depth, alpha, batch, seed):
     fx["g_upstream_noise"] = np.array(rel(r32["g_upstream"], r64["g_upstream"]))
     fx["g_upstream_sub"] = subsample(r64["g_upstream"], 2048)
     fx["g_upstream_sub32"] = subsample(r32["g_upstream"], 2048)
+    for term in ("real", "fake", "gp"):
+        for k, v in r64["d_terms"][term].items():
+            if v is None:
+                continue
+            fx[f"d_term_{term}_norm.{k}"] = np.array(float(v.norm()))
+            fx[f"d_term_{term}_sub.{k}"] = subsample(v)
+            fx[f"d_term_{term}_sub32.{k}"] = subsample(r32["d_terms"][term][k])
+            fx[f"d_term_{term}_noise.{k}"] = np.array(rel(r32["d_terms"][term][k], v))
     worst_noise = 0.0
     for gk in ("d_grads", "g_grads"):
         for k, v in r64[gk].items():
