@@ -10,11 +10,15 @@
 // which keeps the 32 main samples 16-byte aligned for vector LDS stores.
 //
 // MFMA mapping (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain):
-//   forward/dgrad:  D[co][t]  += A[co][k] * B[k][t],  k = (ci, tap)
+//   forward/dgrad:  D[t][co]  += A[t][k] * B[k][co],  k = (ci, tap)
 //   wgrad:          D[co][ci] += A[co][k] * B[k][ci], k = (sample, t), one D per tap
-// With time on the MFMA column (= lane) axis every accumulator register is a run of
-// 32 consecutive time steps of one output channel: 128-byte coalesced stores.
+// With time on the MFMA row axis a lane owns one output channel and its 16 accumulator
+// registers are four runs of 4 consecutive time steps: 16-byte stores (4-byte-per-lane stores
+// are issue-bound on this chip and cost more than the MFMAs of a 64-channel tile).
 #include "common.h"
+
+#include <cstdlib>
+#include <type_traits>
 
 namespace eeggan {
 namespace {
@@ -38,6 +42,7 @@ struct ConvArgs {
     float act_param;
     const float* act_aux;
     int vec;  // T % 4 == 0: 16-byte global loads are aligned
+    int debug;  // timing experiments only (EEGGAN_DEBUG): 1 no MFMA, 2 no restaging, 4 no stores
 };
 
 // ---------------------------------------------------------------------------------------
@@ -151,11 +156,10 @@ struct XStage {
 // channels x NT 32-wide subtiles; a chunk is CK = 32 input channels.  Per step the weight chunk
 // [CT][CK*K] and the activation chunk [CK][NT*40] are staged global -> registers -> LDS into the
 // buffer the NEXT step reads (two LDS buffers, loads issued before the MFMA block and written
-// after it), so one barrier per step suffices and global latency hides under 48-96 MFMAs.
-//   K taps (1|3);  WM x WN wave grid over (32-channel row tiles x subtiles);  VEC: T % 4 == 0.
-constexpr int CK = 32;
-
-template <int K, int CT, int NT, int WM, int WN, bool VEC>
+// after it), so one barrier per step suffices and global latency hides under the MFMAs.
+//   K taps (1|3);  CK input channels per chunk;  WM x WN wave grid over (32-channel row tiles x
+//   subtiles);  VEC: T % 4 == 0.
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
@@ -235,99 +239,124 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         }
     };
 
+    // Prefetch ONLY issues loads (from clamped, always-valid addresses) and records validity bits;
+    // every consumer of the loaded values (zeroing of out-of-range items, the fused backward mask,
+    // the equalized-lr scale) runs in commit(), after the MFMA block, so the loads' latency hides
+    // under it.  A predicated load, or a select right behind the load, makes the compiler wait for
+    // the whole prefetch before the first MFMA.
+    f32x4 mv[VEC ? XV : 1];   // mask_y values of the activation items (VEC path)
+    float mdv[XV], mhv[HV], mdh[HV];
+    unsigned okbits = 0;      // bit i: weight item i valid; bit 8+i: activation item i; bit 16+i: halo i
+    int p_lim = 0;
+
     auto prefetch = [&]() {  // global -> registers for step (p_tile, p_chunk)
         const int ci0 = p_chunk * CK;
-        // weights
+        okbits = 0;
         if (wvec) {
 #pragma unroll
             for (int i = 0; i < WV; ++i) {
                 const int co = p_co0 + w_row[i];
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (co < a.Cout)
-                    v = *reinterpret_cast<const f32x4*>(a.w + ((long long)co * a.Cin + ci0) * K + 4 * w_q[i]);
-                wv[i] = v;
+                const bool ok = co < a.Cout;
+                okbits |= ok ? (1u << i) : 0u;
+                const long long off = ok ? ((long long)co * a.Cin + ci0) * K + 4 * w_q[i] : 0;
+                wv[i] = *reinterpret_cast<const f32x4*>(a.w + off);
             }
         } else {
-            const int lim = (a.Cin - ci0) * K;  // valid floats of this chunk per weight row
+            p_lim = (a.Cin - ci0) * K;  // valid floats of this chunk per weight row
 #pragma unroll
             for (int i = 0; i < WV; ++i) {
                 const int co = p_co0 + w_row[i];
-                const float* src = a.w + ((long long)co * a.Cin + ci0) * K + 4 * w_q[i];
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const bool rok = co < a.Cout;
+                okbits |= rok ? (1u << i) : 0u;
+                const long long base = ((long long)co * a.Cin + ci0) * K + 4 * w_q[i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (co < a.Cout && 4 * w_q[i] + e < lim) v[e] = src[e];
-                wv[i] = v;
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = rok && 4 * w_q[i] + e < p_lim;
+                    wv[i][e] = a.w[ok ? base + e : 0];
+                }
             }
         }
-        // activations (optionally times the backward mask of the producing layer)
         const long long coff = (long long)ci0 * a.T;
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int c = ci0 + x_row0 + i * XROWS;
             const long long off = x_off + coff + (long long)(i * XROWS) * a.T;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (x_ok && c < a.Cin) {
-                if (VEC) {
-                    v = *reinterpret_cast<const f32x4*>(a.x + off);
-                    if (a.mask_y) {
-                        const f32x4 my = *reinterpret_cast<const f32x4*>(a.mask_y + off);
-                        const float md = a.mask_drop ? a.mask_drop[x_b * a.Cin + c] : 1.f;
+            const bool ok = x_ok && c < a.Cin;
+            okbits |= ok ? (1u << (8 + i)) : 0u;
+            if (VEC) {
+                const long long o = ok ? off : 0;
+                xv[i] = *reinterpret_cast<const f32x4*>(a.x + o);
+                if (a.mask_y) {  // wave-uniform
+                    mv[VEC ? i : 0] = *reinterpret_cast<const f32x4*>(a.mask_y + o);
+                    mdv[i] = a.mask_drop ? a.mask_drop[ok ? x_b * a.Cin + c : 0] : 1.f;
+                }
+            } else {
+                const int t = (int)((x_off - ((long long)x_b * a.Cin + x_row0) * a.T));
+                const float md = (a.mask_y && a.mask_drop) ? a.mask_drop[ok ? x_b * a.Cin + c : 0] : 1.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? md : md * a.mask_slope;
-                    }
-                } else {
-                    const int t = (int)((x_off - ((long long)x_b * a.Cin + x_row0) * a.T));
-                    const float md = (a.mask_y && a.mask_drop) ? a.mask_drop[x_b * a.Cin + c] : 1.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (t + e < a.T) {
-                            float u = a.x[off + e];
-                            if (a.mask_y) u *= a.mask_y[off + e] > 0.f ? md : md * a.mask_slope;
-                            v[e] = u;
-                        }
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const bool oke = ok && t + e < a.T;
+                    const long long o = oke ? off + e : 0;
+                    float u = a.x[o];
+                    if (a.mask_y) u *= a.mask_y[o] > 0.f ? md : md * a.mask_slope;
+                    xv[i][e] = oke ? u : 0.f;  // (rare path: T % 4 != 0)
                 }
             }
-            xv[i] = v;
         }
         if (K > 1) {
 #pragma unroll
             for (int i = 0; i < HV; ++i) {
                 const int row = h_row0 + i * HROWS;
                 const int c = ci0 + row;
-                float u = 0.f;
-                if (h_ok && row < CK && c < a.Cin) {
-                    const long long off = h_off + coff + (long long)(i * HROWS) * a.T;
-                    u = a.x[off];
-                    if (a.mask_y) {
-                        const float md = a.mask_drop ? a.mask_drop[h_b * a.Cin + c] : 1.f;
-                        u *= a.mask_y[off] > 0.f ? md : md * a.mask_slope;
-                    }
+                const bool ok = h_ok && row < CK && c < a.Cin;
+                okbits |= ok ? (1u << (16 + i)) : 0u;
+                const long long off = ok ? h_off + coff + (long long)(i * HROWS) * a.T : 0;
+                hv[i] = a.x[off];
+                if (a.mask_y) {
+                    mhv[i] = a.mask_y[off];
+                    mdh[i] = a.mask_drop ? a.mask_drop[ok ? h_b * a.Cin + c : 0] : 1.f;
                 }
-                hv[i] = u;
             }
         }
     };
 
-    auto commit = [&](float* buf) {  // registers -> LDS buffer
+    auto commit = [&](float* buf) {  // registers -> LDS buffer (all consumers of the prefetch live here)
         float* Ws = buf;
         float* Xs = buf + CT * WLD;
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
+            const bool ok = (okbits >> i) & 1u;
             f32x4 v = wv[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
+            for (int e = 0; e < 4; ++e) {
+                const bool oke = ok && (wvec || 4 * w_q[i] + e < p_lim);
+                v[e] = oke ? v[e] * a.in_scale : 0.f;
+            }
             *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < XV; ++i)
-            *reinterpret_cast<f32x4*>(Xs + (x_row0 + i * XROWS) * XLD + x_n * SUB + 4 + 4 * x_q) = xv[i];
+        for (int i = 0; i < XV; ++i) {
+            const bool ok = (okbits >> (8 + i)) & 1u;
+            f32x4 v = xv[i];
+            if (VEC) {
+                if (a.mask_y) {
+                    const f32x4 my = mv[VEC ? i : 0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? mdv[i] : mdv[i] * a.mask_slope;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(Xs + (x_row0 + i * XROWS) * XLD + x_n * SUB + 4 + 4 * x_q) = v;
+        }
         if (K > 1) {
 #pragma unroll
             for (int i = 0; i < HV; ++i) {
                 const int row = h_row0 + i * HROWS;
-                if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = hv[i];
+                const bool ok = (okbits >> (16 + i)) & 1u;
+                float u = hv[i];
+                if (a.mask_y) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
+                if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = ok ? u : 0.f;
             }
         }
     };
@@ -354,11 +383,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 p_tile += gridDim.x;
                 setup_tile(p_tile);
             }
-            prefetch();
+            if (!(a.debug & 2)) prefetch();
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
         }
         const float* buf = smem + (step & 1) * BUF;
         const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
         const float* Bp = buf + CT * WLD + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
+        if (!(a.debug & 1))
 #pragma unroll
         for (int s4 = 0; s4 < KH / 4; ++s4) {
             f32x4 av[RM];
@@ -376,47 +407,98 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
                     for (int n = 0; n < RN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][u], bv[n], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n], av[i][u], acc[i][n], 0, 0, 0);
             }
         }
         if (c_chunk + 1 == nchunks) {
-            // epilogue of the finished tile: bias -> activation -> per-(sample, channel) multiplier
+            // epilogue of the finished tile: bias -> activation -> per-(sample, channel) multiplier.
+            // The activation is dispatched once (wave-uniform); optional operands are read through
+            // an always-valid pointer and neutralised by a select, so the 16*RM*RN stores of a
+            // lane are straight-line code.
             const int ty = c_tile / tiles_x, tx = c_tile - ty * tiles_x;
             const int co0 = ty * CT;
+            const bool full = co0 + CT <= a.Cout;
+            const bool has_bias = a.bias != nullptr, has_drop = a.drop != nullptr;
+            const float* bp = has_bias ? a.bias : a.w;
+            const float* dp = has_drop ? a.drop : a.w;
+            auto run = [&](auto tag) {
+                constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-            for (int n = 0; n < RN; ++n) {
-                const int sub = tx * NT + wn * RN + n;
-                const int b = sub / a.ST;
-                const int t = (sub - b * a.ST) * 32 + l31;
-                const bool ok = sub < a.NS && t < a.T;
+                for (int n = 0; n < RN; ++n) {
+                    const int sub = tx * NT + wn * RN + n;
+                    const int b = sub / a.ST;
+                    const int t0 = (sub - b * a.ST) * 32 + 4 * h;
+                    const bool sok = sub < a.NS;
 #pragma unroll
-                for (int i = 0; i < RM; ++i) {
+                    for (int i = 0; i < RM; ++i) {
+                        // accumulator layout: lane = output channel, register r = time (r&3) + 8*(r>>2) + 4*h,
+                        // i.e. four runs of 4 consecutive time steps per lane: 16-byte stores
+                        const int co = co0 + (wm * RM + i) * 32 + l31;
+                        const bool cok = sok && (full || co < a.Cout);
+                        const int cc = cok ? co : 0;
+                        const int bc = cok ? b : 0;
+                        const float bb = has_bias ? bp[cc] : 0.f;
+                        const float dd = has_drop ? dp[bc * a.Cout + cc] : 1.f;
+                        const long long row = ((long long)bc * a.Cout + cc) * a.T;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = co0 + (wm * RM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (ok && co < a.Cout) {
-                            float v = acc[i][n][r];
-                            const long long o = ((long long)b * a.Cout + co) * a.T + t;
-                            if (a.bias) v += a.bias[co];
-                            if (a.act == EEGGAN_ACT_LRELU)
-                                v = v > 0.f ? v : v * a.act_param;
-                            else if (a.act == EEGGAN_ACT_TANH)
-                                v = tanhf(v * a.act_param);
-                            else if (a.act == EEGGAN_ACT_MASK)
-                                v = a.act_aux[o] > 0.f ? v : v * a.act_param;
-                            if (a.drop) v *= a.drop[b * a.Cout + co];
-                            a.y[o] = v;
+                        for (int q = 0; q < 4; ++q) {
+                            const int t = t0 + 8 * q;
+                            const bool ok = cok && t < a.T;
+                            const long long o = row + (ok ? t : 0);
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][n][4 * q + e] + bb;
+                            if (ACT == EEGGAN_ACT_LRELU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_param;
+                            }
+                            if (ACT == EEGGAN_ACT_TANH) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e] * a.act_param);
+                            }
+                            if (ACT == EEGGAN_ACT_MASK) {
+                                if (VEC) {
+                                    const f32x4 m = *reinterpret_cast<const f32x4*>(a.act_aux + o);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * a.act_param;
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float m = a.act_aux[(ok && t + e < a.T) ? o + e : row];
+                                        v[e] = m > 0.f ? v[e] : v[e] * a.act_param;
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= dd;
+                            if (!(a.debug & 4)) {
+                                if (VEC) {
+                                    if (ok) *reinterpret_cast<f32x4*>(a.y + o) = v;
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (ok && t + e < a.T) a.y[o + e] = v[e];
+                                }
+                            }
                         }
-                        acc[i][n][r] = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
                     }
                 }
+            };
+            switch (a.act) {
+                case EEGGAN_ACT_LRELU: run(std::integral_constant<int, EEGGAN_ACT_LRELU>{}); break;
+                case EEGGAN_ACT_TANH: run(std::integral_constant<int, EEGGAN_ACT_TANH>{}); break;
+                case EEGGAN_ACT_MASK: run(std::integral_constant<int, EEGGAN_ACT_MASK>{}); break;
+                default: run(std::integral_constant<int, EEGGAN_ACT_NONE>{}); break;
             }
             c_chunk = 0;
             c_tile += gridDim.x;
         } else {
             ++c_chunk;
         }
-        if (more) commit(smem + ((step + 1) & 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);  // ... and their consumers below it
+        if (more && !(a.debug & 2)) commit(smem + ((step + 1) & 1) * BUF);
         __syncthreads();
     }
 }
@@ -432,24 +514,27 @@ int num_cus() {
     return cus;
 }
 
-template <int K, int CT, int NT, int WM, int WN, bool VEC>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (CT * (CK * K + 4) + CK * NT * SUB) * sizeof(float);
-    static bool configured = false;  // opt in to more than 64 KiB of dynamic LDS, once per kernel
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<K, CT, NT, WM, WN, VEC>),
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC>;
+    static int per_cu = 0;  // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once)
+    if (per_cu == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv1d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
             return 1;
         }
-        configured = true;
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 256, lds) != hipSuccess || n < 1)
+            n = 1;
+        per_cu = n > 4 ? 4 : n;
     }
     const long long ntiles = (long long)((a.NS + NT - 1) / NT) * ((a.Cout + CT - 1) / CT);
-    const long long per_cu = lds <= 80 * 1024 ? 2 : 1;
     long long grid = (long long)num_cus() * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((conv_fwd_kernel<K, CT, NT, WM, WN, VEC>), dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("conv1d");
 }
 
@@ -459,10 +544,17 @@ template <int K>
 int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     const long long ns = a.NS;
     auto tiles = [&](int ct, int nt) { return ((ns + nt - 1) / nt) * ((a.Cout + ct - 1) / ct); };
-    if (!a.vec) return launch_fwd<K, 64, 2, 2, 2, false>(a, st);
-    if (a.Cout <= 32) return launch_fwd<K, 32, 8, 1, 4, true>(a, st);
-    if (tiles(64, 4) >= num_cus()) return launch_fwd<K, 64, 4, 1, 4, true>(a, st);
-    return launch_fwd<K, 64, 2, 2, 2, true>(a, st);
+    if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
+    if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
+    if (K == 3) {
+        static const int cfg = getenv("EEGGAN_CFG") ? atoi(getenv("EEGGAN_CFG")) : -1;
+        if (cfg == 0) return launch_fwd<3, 64, 4, 32, 1, 4, true>(a, st);
+        if (cfg == 1) return launch_fwd<3, 64, 2, 32, 2, 2, true>(a, st);
+        if (cfg == 2) return launch_fwd<3, 64, 4, 16, 1, 4, true>(a, st);
+        if (cfg == 3) return launch_fwd<3, 64, 2, 16, 2, 2, true>(a, st);
+    }
+    if (tiles(64, 4) >= num_cus()) return launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
+    return launch_fwd<K, 64, 2, 32, 2, 2, true>(a, st);
 }
 
 __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
@@ -671,6 +763,8 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     a.NS = B * a.ST;
     a.in_scale = in_scale; a.act = act; a.act_param = act_param; a.act_aux = act_aux;
     a.vec = (T % 4 == 0) ? 1 : 0;
+    static const int dbg = getenv("EEGGAN_DEBUG") ? atoi(getenv("EEGGAN_DEBUG")) : 0;
+    a.debug = dbg;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
 }

@@ -19,7 +19,9 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) * 1e-3 / n
 
 print(f"{'shape':>22s} {'fwd us':>8s} {'TF':>6s} {'dgrad us':>9s} {'TF':>6s} {'wgrad us':>9s} {'TF':>6s}")
+marker = torch.zeros(8, device=dev)
 for cin, cout, T, K in shapes:
+    ops.pow_base_raw(marker, 2.0)  # run separator in kernel traces
     x = torch.randn(B, cin, T, device=dev); w = torch.randn(cout, cin, K, device=dev)
     b = torch.randn(cout, device=dev); r = torch.rand(B, cout, device=dev) + 0.5
     gy = torch.randn(B, cout, T, device=dev)
