@@ -38,15 +38,17 @@ def parse():
                     help="'device': GDrop noise drawn on the GPU (same distribution); "
                          "'numpy': the reference's host RNG stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying HIP graphs")
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=BATCH)
     return ap.parse_args()
 
 
-def make_trainer(dev, depth, alpha, batch, seed, world, rank):
+def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False):
     from eeggan_amd import config, layers
     from eeggan_amd.optim import Adam
     from eeggan_amd.parallel import DataParallelStep
+    from eeggan_amd.graphs import GraphedTrainer
     from eeggan_amd.trainer import Trainer
     from oracle.ref_cpu import synthetic_eeg  # input synthesis only (same generator as the CPU leg)
 
@@ -76,7 +78,8 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank):
         model_depth, alpha = depth, 1.0
 
     d_loss, g_loss = config.loss_closures()
-    tr = Trainer(d, g, d_loss, g_loss, _DS(), latents(), 0, opt_g, opt_d)
+    cls = Trainer if (eager or world > 1 or layers.get_drop_mode() != "device") else GraphedTrainer
+    tr = cls(d, g, d_loss, g_loss, _DS(), latents(), 0, opt_g, opt_d)
     tr.dataiter = reals()
     tr.grad_sync = DataParallelStep() if world > 1 else None
     return tr
@@ -151,7 +154,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     from eeggan_amd import layers
     layers.set_drop_mode(args.drop_mode)
-    tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank)
+    tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank, args.eager)
 
     def barrier():
         if dist is not None:
@@ -180,7 +183,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha=1, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
-                       "parallelism": f"dp{world}", "drop_noise": args.drop_mode, "step_flop": None},
+                       "parallelism": f"dp{world}", "drop_noise": args.drop_mode,
+                       "launch": type(tr).__name__},
         }
         out["roofline"] = conv_roofline(dev, args.batch, T)
         if world == 1 and not args.no_cpu_baseline:

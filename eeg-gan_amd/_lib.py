@@ -53,8 +53,8 @@ SIGNATURES = {
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_mean_scale_bwd": (_i, [_f, _f, _i, _fl, _st]),
-    "eeggan_adam_step": (_i, [_f, C.c_void_p, _i, _fl, _fl, _fl, _fl, _i, _fl, _st]),
-    "eeggan_multi_copy": (_i, [_f, C.c_void_p, _i, _st]),
+    "eeggan_adam_step": (_i, [C.c_void_p, _i, _fl, _fl, _fl, _fl, _fl, _st]),
+    "eeggan_multi_copy": (_i, [C.c_void_p, _i, _st]),
 }
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_MASK = 0, 1, 2, 3

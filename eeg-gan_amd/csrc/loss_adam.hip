@@ -1,7 +1,6 @@
 // WGAN-GP loss reductions and the multi-tensor Adam / bucket-copy kernels.
 #include "common.h"
 
-#include <vector>
 
 namespace eeggan {
 namespace {
@@ -70,14 +69,21 @@ __global__ __launch_bounds__(256) void mean_scale_bwd_kernel(const float* __rest
 }
 
 // ---- multi-tensor kernels ---------------------------------------------------------------------
-// A workgroup owns one CHUNK of one tensor; it finds its tensor by walking the (short) table.
+// The descriptor table travels BY VALUE in the kernel arguments (<= 64 tensors, 3 KiB): no device
+// table, no host->device copy, and a captured launch keeps its pointers.  A workgroup owns one
+// CHUNK of one tensor and finds it by walking the table.
 constexpr int64_t CHUNK = 256 * 4 * 4;
+constexpr int MAXT = 64;
 
-__device__ __forceinline__ bool locate(const eeggan_adam_tensor* __restrict__ table, int ntensors, int64_t blk,
-                                       int* ti, int64_t* start) {
+struct Pack {
+    eeggan_adam_tensor t[MAXT];
+    int n;
+};
+
+__device__ __forceinline__ bool locate(const Pack& pk, int64_t blk, int* ti, int64_t* start) {
     int64_t acc = 0;
-    for (int i = 0; i < ntensors; ++i) {
-        const int64_t nb = (table[i].n + CHUNK - 1) / CHUNK;
+    for (int i = 0; i < pk.n; ++i) {
+        const int64_t nb = (pk.t[i].n + CHUNK - 1) / CHUNK;
         if (blk < acc + nb) {
             *ti = i;
             *start = (blk - acc) * CHUNK;
@@ -88,13 +94,18 @@ __device__ __forceinline__ bool locate(const eeggan_adam_tensor* __restrict__ ta
     return false;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const eeggan_adam_tensor* __restrict__ table, int ntensors,
-                                                   float lr_c, float b1, float b2, float eps, float inv_sqrt_bc2,
-                                                   float grad_scale) {
+// The step counters live on the device (one float per tensor) so that a captured launch advances
+// them at every replay; this kernel reads the OLD count and uses count + 1, adam_tick_kernel
+// (launched right behind it) stores the increment.
+__global__ __launch_bounds__(256) void adam_kernel(Pack pk, float lr, float b1, float b2, float eps, float grad_scale) {
     int ti;
     int64_t start;
-    if (!locate(table, ntensors, blockIdx.x, &ti, &start)) return;
-    const eeggan_adam_tensor t = table[ti];
+    if (!locate(pk, blockIdx.x, &ti, &start)) return;
+    const eeggan_adam_tensor t = pk.t[ti];
+    const float step = t.step[0] + 1.f;
+    const float bc1 = 1.f - powf(b1, step);
+    const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, step));
+    const float lr_c = lr / bc1;
     int64_t end = start + CHUNK;
     if (end > t.n) end = t.n;
     for (int64_t i = start + threadIdx.x; i < end; i += 256) {
@@ -107,20 +118,31 @@ __global__ __launch_bounds__(256) void adam_kernel(const eeggan_adam_tensor* __r
     }
 }
 
-__global__ __launch_bounds__(256) void multi_copy_kernel(const eeggan_adam_tensor* __restrict__ table, int ntensors) {
+__global__ void adam_tick_kernel(Pack pk) {
+    const int i = threadIdx.x;
+    if (i < pk.n) pk.t[i].step[0] += 1.f;
+}
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(Pack pk) {
     int ti;
     int64_t start;
-    if (!locate(table, ntensors, blockIdx.x, &ti, &start)) return;
-    const eeggan_adam_tensor t = table[ti];
+    if (!locate(pk, blockIdx.x, &ti, &start)) return;
+    const eeggan_adam_tensor t = pk.t[ti];
     int64_t end = start + CHUNK;
     if (end > t.n) end = t.n;
     for (int64_t i = start + threadIdx.x; i < end; i += 256) t.p[i] = t.g[i];
 }
 
-int64_t total_blocks(const int64_t* sizes_host, int ntensors) {
-    int64_t nb = 0;
-    for (int i = 0; i < ntensors; ++i) nb += (sizes_host[i] + CHUNK - 1) / CHUNK;
-    return nb;
+int make_pack(const char* what, const eeggan_adam_tensor* table, int first, int ntensors, Pack* pk, int64_t* blocks) {
+    pk->n = ntensors - first < MAXT ? ntensors - first : MAXT;
+    *blocks = 0;
+    for (int i = 0; i < pk->n; ++i) {
+        pk->t[i] = table[first + i];
+        EEGGAN_REQUIRE(pk->t[i].n > 0 && pk->t[i].p && pk->t[i].g, "%s: bad descriptor %d", what, first + i);
+        *blocks += (pk->t[i].n + CHUNK - 1) / CHUNK;
+    }
+    EEGGAN_REQUIRE(*blocks < (1ll << 31), "%s: too many elements", what);
+    return 0;
 }
 
 }  // namespace
@@ -166,24 +188,33 @@ extern "C" int eeggan_mean_scale_bwd(const float* gl, float* out, int n, float s
     return check_launch("mean_scale_bwd");
 }
 
-extern "C" int eeggan_adam_step(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors, float lr,
-                                float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
-    EEGGAN_REQUIRE(table && sizes_host && ntensors > 0, "adam_step: bad table");
-    EEGGAN_REQUIRE(step >= 1, "adam_step: step must be >= 1 (got %d)", step);
-    const int64_t nb = total_blocks(sizes_host, ntensors);
-    EEGGAN_REQUIRE(nb > 0 && nb < (1ll << 31), "adam_step: bad total size");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), table, ntensors,
-                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
-    return check_launch("adam_step");
+extern "C" int eeggan_adam_step(const eeggan_adam_tensor* table, int ntensors, float lr, float beta1, float beta2,
+                                float eps, float grad_scale, void* stream) {
+    EEGGAN_REQUIRE(table && ntensors > 0, "adam_step: bad table");
+    EEGGAN_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: betas outside [0, 1)");
+    for (int first = 0; first < ntensors; first += MAXT) {
+        Pack pk;
+        int64_t nb;
+        if (make_pack("adam_step", table, first, ntensors, &pk, &nb)) return 1;
+        for (int i = 0; i < pk.n; ++i)
+            EEGGAN_REQUIRE(pk.t[i].m && pk.t[i].v && pk.t[i].step, "adam_step: descriptor %d lacks state pointers", first + i);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), pk, lr, beta1, beta2, eps,
+                           grad_scale);
+        if (check_launch("adam_step")) return 1;
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(MAXT), 0, as_stream(stream), pk);
+        if (check_launch("adam_step tick")) return 1;
+    }
+    return 0;
 }
 
-extern "C" int eeggan_multi_copy(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors,
-                                 void* stream) {
-    EEGGAN_REQUIRE(table && sizes_host && ntensors > 0, "multi_copy: bad table");
-    const int64_t nb = total_blocks(sizes_host, ntensors);
-    EEGGAN_REQUIRE(nb > 0 && nb < (1ll << 31), "multi_copy: bad total size");
-    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), table, ntensors);
-    return check_launch("multi_copy");
+extern "C" int eeggan_multi_copy(const eeggan_adam_tensor* table, int ntensors, void* stream) {
+    EEGGAN_REQUIRE(table && ntensors > 0, "multi_copy: bad table");
+    for (int first = 0; first < ntensors; first += MAXT) {
+        Pack pk;
+        int64_t nb;
+        if (make_pack("multi_copy", table, first, ntensors, &pk, &nb)) return 1;
+        hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), pk);
+        if (check_launch("multi_copy")) return 1;
+    }
+    return 0;
 }

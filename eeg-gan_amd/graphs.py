@@ -1,0 +1,137 @@
+"""HIP-graph execution of the training step.
+
+At the final stage one ``Trainer.train()`` enqueues ~4000 kernels; launched one by one from Python
+the host (autograd bookkeeping + one C-ABI call per kernel) takes longer than the GPU.  Every entry
+point of the kernel library only enqueues work on the current stream (no allocation, no copies,
+no synchronisation), the optimizer keeps its step counters on the device and the GDrop noise can be
+drawn on the device, so a whole discriminator iteration (three critic passes, the gradient-penalty
+double backward, backward, Adam) and a whole generator iteration can each be captured once into a
+hipGraph and replayed with fresh inputs copied into static buffers.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import layers, ops
+from .trainer import Trainer
+from .utils import cudize
+
+
+class GraphedCall:
+    """Capture ``fn()`` into a HIP graph after ``warmup`` eager runs on a side stream.  ``fn`` must
+    read its inputs from tensors that stay alive and at the same address (static buffers)."""
+
+    def __init__(self, fn: Callable[[], torch.Tensor], warmup: int = 3):
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        ops.bump_weights_epoch()  # every derived weight view is rebuilt inside the captured region
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
+def _snapshot(modules, optimizers):
+    params = [(p, p.detach().clone()) for m in modules for p in m.parameters()]
+    states = []
+    for opt in optimizers:
+        for p, st in opt.state.items():
+            states.append((opt, p, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}))
+    had = [(opt, set(opt.state.keys())) for opt in optimizers]
+    return params, states, had
+
+
+def _restore(snap):
+    params, states, had = snap
+    with torch.no_grad():
+        for p, v in params:
+            p.copy_(v)
+        for opt, p, st in states:
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    opt.state[p][k].copy_(v)
+        for opt, keys in had:  # state created by the warm-up runs starts from zero again
+            for p, st in opt.state.items():
+                if p not in keys:
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+    ops.bump_weights_epoch()
+
+
+class GraphedTrainer(Trainer):
+    """``Trainer`` whose discriminator and generator iterations replay captured HIP graphs.
+
+    Graphs are (re)captured whenever (depth, alpha, batch shape, optimizers) change; the warm-up
+    runs needed for capture are undone (parameters and optimizer state are restored), so the
+    sequence of updates equals the eager trainer's.  While alpha < 1 (fade-in) alpha changes at
+    every iteration and is a kernel argument, so those iterations run eagerly.  Requires the
+    device noise mode (``layers.set_drop_mode('device')``): host RNG draws cannot be captured."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._key = None
+        self._d_call: Optional[GraphedCall] = None
+        self._g_call: Optional[GraphedCall] = None
+        self._real: Optional[torch.Tensor] = None
+        self._z: Optional[torch.Tensor] = None
+
+    def _capture(self, real, z, key):
+        if layers.get_drop_mode() != "device":
+            raise RuntimeError("GraphedTrainer needs layers.set_drop_mode('device')")
+        if self.grad_sync is not None:
+            raise NotImplementedError("graph capture of the data-parallel step is not supported yet")
+        self._real, self._z = real.clone(), z.clone()
+        snap = _snapshot([self.discriminator, self.generator], [self.optimizer_d, self.optimizer_g])
+
+        def d_iter():
+            loss = self.d_loss(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
+            loss.backward()
+            self.optimizer_d.step()
+            return loss.detach()
+
+        def g_iter():
+            loss = self.g_loss(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
+            loss.backward()
+            self.optimizer_g.step()
+            return loss.detach()
+
+        self._d_call = GraphedCall(d_iter)
+        self._g_call = GraphedCall(g_iter)
+        _restore(snap)
+        self._key = key
+
+    def train(self):
+        gen, dis = self.generator, self.discriminator
+        if gen.alpha != 1.0 or self.grad_sync is not None or self.lr_scheduler_d is not None \
+                or self.lr_scheduler_g is not None:
+            self._key = None
+            return super().train()
+        z = cudize(next(self.random_latents_generator))["z"]
+        d_loss = None
+        for _ in range(self.d_training_repeats):
+            real = cudize(next(self.dataiter))["x"]
+            key = (gen.depth, tuple(real.shape), tuple(z.shape), id(self.optimizer_d), id(self.optimizer_g),
+                   self.optimizer_d.param_groups[0]["lr"], self.optimizer_g.param_groups[0]["lr"])
+            if key != self._key:
+                self._capture(real, z, key)
+            self.cur_nimg += real.size(0)
+            self._real.copy_(real)
+            self._z.copy_(z)
+            d_loss = self._d_call()
+            z = cudize(next(self.random_latents_generator))["z"]
+        self._z.copy_(z)
+        g_loss = self._g_call()
+        self.iterations += 1
+        self.call_plugins("iteration", self.iterations, *(g_loss, d_loss))

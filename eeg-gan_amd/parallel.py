@@ -56,10 +56,8 @@ class GradBucket:
         rows = []
         for p in self.params:
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            rows.append((self.views[p].data_ptr(), g.data_ptr(), 0, 0, p.numel()))
-        table, sizes = optim.build_table(rows, self.flat.device)
-        call("eeggan_multi_copy", table.data_ptr(), sizes.ctypes.data, len(rows),
-             torch.cuda.current_stream().cuda_stream)
+            rows.append((self.views[p].data_ptr(), g.data_ptr(), 0, 0, 0, p.numel()))
+        call("eeggan_multi_copy", optim.build_table(rows), len(rows), torch.cuda.current_stream().cuda_stream)
 
 
 class DataParallelStep:

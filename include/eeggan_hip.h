@@ -153,21 +153,21 @@ int eeggan_mean_scale(const float* v, float* out, int n, float scale, void* stre
 int eeggan_mean_scale_bwd(const float* gl, float* out, int n, float scale, void* stream);
 
 /* ---- multi-tensor Adam (torch.optim.Adam built at train.py:131-136, stepped at trainer.py:90,94)
- * table: DEVICE array of `ntensors` descriptors; sizes_host: HOST array of the same n's (used
- * only to size the grid); one launch updates every tensor:
- *   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ * table: HOST array of `ntensors` descriptors (copied into the kernel arguments, so the call is
+ * graph-capturable and needs no device table); one launch per 64 tensors updates all of them:
+ *   step += 1;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
  *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
- * grad_scale multiplies every gradient first (1/world_size after a summed all-reduce). */
+ * `step` points to a DEVICE float holding that tensor's step count (advanced by the call, so a
+ * captured launch counts correctly on every replay).  grad_scale multiplies every gradient first
+ * (1/world_size after a summed all-reduce). */
 typedef struct {
-    float* p; const float* g; float* m; float* v; int64_t n;
+    float* p; const float* g; float* m; float* v; float* step; int64_t n;
 } eeggan_adam_tensor;
-int eeggan_adam_step(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors,
-                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
-                     void* stream);
-/* dst_flat[offset_i + k] = src_i[k] for every tensor of the table (p = dst slice, g = src):
- * packs gradients into one bucket for a single all-reduce (or unpacks with swapped roles). */
-int eeggan_multi_copy(const eeggan_adam_tensor* table, const int64_t* sizes_host, int ntensors,
-                      void* stream);
+int eeggan_adam_step(const eeggan_adam_tensor* table, int ntensors,
+                     float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* p[k] = g[k] for every tensor of the table (m, v, step unused): packs gradients into the slices
+ * of one flat bucket for a single all-reduce. */
+int eeggan_multi_copy(const eeggan_adam_tensor* table, int ntensors, void* stream);
 
 #ifdef __cplusplus
 }

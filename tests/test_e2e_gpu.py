@@ -241,3 +241,51 @@ def test_full_step_fixture(dev):
             tol = max(2e-3, 2.0 * float(fx[f"{net}_delta_noise.{k}"]))
             e = rel(subsample(delta), fx[f"{net}_delta_sub.{k}"])
             assert e < tol, f"{net}.{k}: update differs by {e:.3e} (tolerance {tol:.3e})"
+
+
+def test_graph_replay_equals_eager(dev):
+    """Two training steps through captured HIP graphs move the weights exactly like eager launches
+    (noise off and fixed mixing factors, so that both runs see the same random inputs)."""
+    from eeggan_amd import config, layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.layers import GDropLayer
+    from eeggan_amd.optim import Adam
+    from eeggan_amd.trainer import Trainer
+    depth, B = 2, 8
+    T = config.seq_len(depth)
+    gen = torch.Generator().manual_seed(4)
+    reals = [torch.randn(B, 5, T, generator=gen).to(dev) for _ in range(10)]
+    zs = [torch.randn(B, 256, generator=gen).to(dev) for _ in range(12)]
+    mix = torch.rand(B, 1, 1, generator=gen).to(dev)
+    results = []
+    layers.set_drop_mode("device")
+    try:
+        for cls in (Trainer, GraphedTrainer):
+            g, d = config.build_models(9)
+            g, d = g.to(dev), d.to(dev)
+            g.depth = d.depth = depth
+            for m in list(g.modules()) + list(d.modules()):
+                if isinstance(m, GDropLayer):
+                    m.strength = 0
+            opt_g = Adam(g.parameters(), 0.002, **config.ADAM)
+            opt_d = Adam(d.parameters(), 0.002, **config.ADAM)
+            d_loss_fn, g_loss_fn = config.loss_closures()
+
+            class _DS:
+                model_depth, alpha = depth, 1.0
+
+            tr = cls(d, g, lambda dis, ge, r, z: d_loss_fn(dis, ge, r, z, mixing=mix), g_loss_fn, _DS(),
+                     iter([{"z": z} for z in zs]), 0, opt_g, opt_d)
+            tr.dataiter = iter([{"x": r} for r in reals])
+            tr.train()
+            tr.train()
+            torch.cuda.synchronize()
+            results.append(({k: v.clone() for k, v in g.state_dict().items()},
+                            {k: v.clone() for k, v in d.state_dict().items()},
+                            float(opt_d.state[next(d.parameters())]["step"]) if False else None))
+    finally:
+        layers.set_drop_mode("numpy")
+    (g0, d0, _), (g1, d1, _) = results
+    for a, b in ((g0, g1), (d0, d1)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"{k} differs between eager and graph replay"

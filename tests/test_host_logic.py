@@ -126,7 +126,8 @@ def test_shard_batch_keeps_minibatch_stddev_groups():
 def test_adam_descriptor_table_layout():
     import ctypes
     from eeggan_amd import optim
-    assert optim.DESC_BYTES == 40  # four pointers + int64, as declared in include/eeggan_hip.h
-    arr = (optim._Desc * 2)()
-    arr[1].n = 7
-    assert bytes(arr)[72:80] == (7).to_bytes(8, "little")
+    assert optim.DESC_BYTES == 48  # five pointers + int64, as declared in include/eeggan_hip.h
+    arr = optim.build_table([(1, 2, 3, 4, 5, 6), (7, 8, 9, 10, 11, 12)])
+    raw = bytes(arr)
+    assert raw[40:48] == (6).to_bytes(8, "little") and raw[48:56] == (7).to_bytes(8, "little")
+    assert raw[88:96] == (12).to_bytes(8, "little")

@@ -296,6 +296,7 @@ def test_adam_matches_torch(dev):
         assert rel(pm, pr) < 1e-6
     sd = om.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][0]["step"]) == 3.0 and float(sd["state"][2]["step"]) == 2.0
 
 
 def test_per_op_golden(dev):
