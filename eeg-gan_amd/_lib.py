@@ -46,9 +46,10 @@ SIGNATURES = {
     "eeggan_mix_batch": (_i, [_f, _f, _f, _f, _i, _sz, _st]),
     "eeggan_pow_base": (_i, [_f, _f, _sz, _fl, _st]),
     "eeggan_resample": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
-    "eeggan_mbstd_fwd": (_i, [_f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_workspace": (_sz, [_i, _i, _i, _i]),
+    "eeggan_mbstd_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
-    "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_wgan_gp_loss_fwd": (_i, [_f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),

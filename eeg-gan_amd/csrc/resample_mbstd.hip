@@ -38,17 +38,32 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 }
 
 // ---- minibatch stddev --------------------------------------------------------------------------
-// One workgroup per group member m; its G samples are b = g*M + m.  n = C*T elements per sample.
+// Group member m owns the G samples b = g*M + m; n = C*T elements per sample.  The element axis is
+// cut into chunks of MB_CHUNK so that the grid (M x chunks) fills the chip (M is only B/4); sums over
+// all elements go through a per-(m, chunk) partial buffer and a tiny finalize kernel, in a fixed order.
 constexpr int MB_MAXG = 8;
+constexpr int MB_CHUNK = 256;
 
-__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int M,
-                                                        int G, int C, int T) {
+__device__ __forceinline__ float group_scale(const float* __restrict__ gout, int m, int M, int G, int n, int T,
+                                             float* red) {
+    // a[m] = (sum over the group's extra-channel gradients) / (n * G)
+    float gs = 0.f;
+    for (int i = threadIdx.x; i < G * T; i += 256) {
+        const int g = i / T, t = i - g * T;
+        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
+    }
+    return block_sum_256(gs, red) / ((float)n * (float)G);
+}
+
+__global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                        float* __restrict__ ws, int M, int G, int C, int T) {
     __shared__ float red[4];
-    const int m = blockIdx.x;
+    const int m = blockIdx.x, chunk = blockIdx.y;
     const int n = C * T;
     const float invG = 1.f / (float)G;
-    float ssum = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    const int e = chunk * MB_CHUNK + threadIdx.x;
+    float sd = 0.f;
+    if (e < n) {
         float v[MB_MAXG];
         float mu = 0.f;
 #pragma unroll
@@ -66,69 +81,72 @@ __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict_
                 var += d * d;
                 out[((long long)(g * M + m)) * (n + T) + e] = v[g];  // channels [0, C) are a copy of x
             }
-        ssum += sqrtf(var * invG);
+        sd = sqrtf(var * invG);
     }
-    const float s = block_sum_256(ssum, red) / (float)n;
+    const float tot = block_sum_256(sd, red);
+    if (threadIdx.x == 0) ws[m * gridDim.y + chunk] = tot;
+}
+
+// out[b, C, t] = scale * sum_chunk ws[m][chunk] for the G samples of member m
+__global__ __launch_bounds__(256) void mbstd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                             int M, int G, int n, int T, int nchunks, float scale) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += 256) s += ws[m * nchunks + i];
+    const float tot = block_sum_256(s, red) * scale;
     for (int i = threadIdx.x; i < G * T; i += 256) {
         const int g = i / T, t = i - g * T;
-        out[((long long)(g * M + m)) * (n + T) + n + t] = s;
+        out[((long long)(g * M + m)) * (n + T) + n + t] = tot;
     }
 }
 
 __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
                                                         float* __restrict__ gx, int M, int G, int C, int T) {
     __shared__ float red[4];
-    const int m = blockIdx.x;
+    const int m = blockIdx.x, chunk = blockIdx.y;
     const int n = C * T;
     const float invG = 1.f / (float)G;
-    float gs = 0.f;
-    for (int i = threadIdx.x; i < G * T; i += 256) {
-        const int g = i / T, t = i - g * T;
-        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
-    }
-    const float a = block_sum_256(gs, red) / ((float)n * (float)G);
-    for (int e = threadIdx.x; e < n; e += 256) {
-        float v[MB_MAXG];
-        float mu = 0.f;
+    const float a = group_scale(gout, m, M, G, n, T, red);
+    const int e = chunk * MB_CHUNK + threadIdx.x;
+    if (e >= n) return;
+    float v[MB_MAXG];
+    float mu = 0.f;
 #pragma unroll
-        for (int g = 0; g < MB_MAXG; ++g)
-            if (g < G) {
-                v[g] = x[((long long)(g * M + m)) * n + e];
-                mu += v[g];
-            }
-        mu *= invG;
-        float var = 0.f;
+    for (int g = 0; g < MB_MAXG; ++g)
+        if (g < G) {
+            v[g] = x[((long long)(g * M + m)) * n + e];
+            mu += v[g];
+        }
+    mu *= invG;
+    float var = 0.f;
 #pragma unroll
-        for (int g = 0; g < MB_MAXG; ++g)
-            if (g < G) {
-                const float d = v[g] - mu;
-                var += d * d;
-            }
-        const float inv_sigma = 1.f / sqrtf(var * invG);
+    for (int g = 0; g < MB_MAXG; ++g)
+        if (g < G) {
+            const float d = v[g] - mu;
+            var += d * d;
+        }
+    const float inv_sigma = 1.f / sqrtf(var * invG);
 #pragma unroll
-        for (int g = 0; g < MB_MAXG; ++g)
-            if (g < G) {
-                const long long b = g * M + m;
-                gx[b * n + e] = gout[b * (n + T) + e] + a * (v[g] - mu) * inv_sigma;
-            }
-    }
+    for (int g = 0; g < MB_MAXG; ++g)
+        if (g < G) {
+            const long long b = g * M + m;
+            gx[b * n + e] = gout[b * (n + T) + e] + a * (v[g] - mu) * inv_sigma;
+        }
 }
 
 __global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
                                                             const float* __restrict__ q, float* __restrict__ ggout,
-                                                            float* __restrict__ gx2, int M, int G, int C, int T) {
+                                                            float* __restrict__ gx2, float* __restrict__ ws, int M,
+                                                            int G, int C, int T) {
     __shared__ float red[4];
-    const int m = blockIdx.x;
+    const int m = blockIdx.x, chunk = blockIdx.y;
     const int n = C * T;
     const float invG = 1.f / (float)G;
-    float gs = 0.f;
-    for (int i = threadIdx.x; i < G * T; i += 256) {
-        const int g = i / T, t = i - g * T;
-        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
-    }
-    const float a = block_sum_256(gs, red) / ((float)n * (float)G);
-    float dsum = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    const float a = group_scale(gout, m, M, G, n, T, red);
+    const int e = chunk * MB_CHUNK + threadIdx.x;
+    float qr = 0.f;  // sum_g q_g * R_g of this element
+    if (e < n) {
         float v[MB_MAXG], qv[MB_MAXG];
         float mu = 0.f, qm = 0.f;
 #pragma unroll
@@ -150,11 +168,9 @@ __global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restr
                 var += d * d;
             }
         const float inv_sigma = 1.f / sqrtf(var * invG);
-        float qr = 0.f;  // sum_g q_g * R_g
 #pragma unroll
         for (int g = 0; g < MB_MAXG; ++g)
             if (g < G) qr += qv[g] * (v[g] - mu) * inv_sigma;
-        dsum += qr;
         const float qrm = qr * invG;
 #pragma unroll
         for (int g = 0; g < MB_MAXG; ++g)
@@ -165,11 +181,8 @@ __global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restr
                 ggout[b * (n + T) + e] = qv[g];
             }
     }
-    const float dtot = block_sum_256(dsum, red) / ((float)n * (float)G);
-    for (int i = threadIdx.x; i < G * T; i += 256) {
-        const int g = i / T, t = i - g * T;
-        ggout[((long long)(g * M + m)) * (n + T) + n + t] = dtot;
-    }
+    const float tot = block_sum_256(qr, red);
+    if (threadIdx.x == 0) ws[m * gridDim.y + chunk] = tot;
 }
 
 int mb_check(const char* what, int B, int C, int T, int group, int* G, int* M) {
@@ -209,12 +222,25 @@ extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* 
     return check_launch("resample");
 }
 
-extern "C" int eeggan_mbstd_fwd(const float* x, float* out, int B, int C, int T, int group, void* stream) {
+extern "C" size_t eeggan_mbstd_workspace(int B, int C, int T, int group) {
+    if (B <= 0 || C <= 0 || T <= 0 || group <= 0) return 0;
+    const int G = B < group ? B : group;
+    const size_t M = (size_t)(B / G), nch = ((size_t)C * T + MB_CHUNK - 1) / MB_CHUNK;
+    return M * nch * sizeof(float);
+}
+
+extern "C" int eeggan_mbstd_fwd(const float* x, float* out, void* workspace, int B, int C, int T, int group,
+                                void* stream) {
     int G, M;
     if (mb_check("mbstd_fwd", B, C, T, group, &G, &M)) return 1;
-    EEGGAN_REQUIRE(x && out, "mbstd_fwd: null pointer");
-    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, out, M, G, C, T);
-    return check_launch("mbstd_fwd");
+    EEGGAN_REQUIRE(x && out && workspace, "mbstd_fwd: null pointer");
+    const int n = C * T, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
+    float* ws = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, C, T);
+    if (check_launch("mbstd_fwd")) return 1;
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, n, T, nch,
+                       1.f / (float)n);
+    return check_launch("mbstd_fwd finalize");
 }
 
 extern "C" int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
@@ -222,16 +248,22 @@ extern "C" int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, in
     int G, M;
     if (mb_check("mbstd_bwd", B, C, T, group, &G, &M)) return 1;
     EEGGAN_REQUIRE(x && gout && gx, "mbstd_bwd: null pointer");
-    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, gout, gx, M, G, C, T);
+    const int nch = (C * T + MB_CHUNK - 1) / MB_CHUNK;
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, gout, gx, M, G, C, T);
     return check_launch("mbstd_bwd");
 }
 
-extern "C" int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2, int B,
-                                    int C, int T, int group, void* stream) {
+extern "C" int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
+                                    void* workspace, int B, int C, int T, int group, void* stream) {
     int G, M;
     if (mb_check("mbstd_bwd_bwd", B, C, T, group, &G, &M)) return 1;
-    EEGGAN_REQUIRE(x && gout && q && ggout && gx2, "mbstd_bwd_bwd: null pointer");
-    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, gout, q, ggout, gx2, M, G, C,
-                       T);
-    return check_launch("mbstd_bwd_bwd");
+    EEGGAN_REQUIRE(x && gout && q && ggout && gx2 && workspace, "mbstd_bwd_bwd: null pointer");
+    const int n = C * T, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
+    float* ws = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(mbstd_bwd_bwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, gout, q, ggout, gx2, ws,
+                       M, G, C, T);
+    if (check_launch("mbstd_bwd_bwd")) return 1;
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, ggout, M, G, n, T, nch,
+                       1.f / ((float)n * (float)G));
+    return check_launch("mbstd_bwd_bwd finalize");
 }

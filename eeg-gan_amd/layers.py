@@ -35,6 +35,39 @@ def get_drop_mode() -> str:
     return _drop_mode
 
 
+class _DropPool:
+    """Device-mode multipliers are drawn CHUNK values at a time (one normal draw + one power kernel)
+    and handed out as slices, instead of two tiny launches per layer and pass.  A chunk is never
+    written again after it is filled, so slices saved for backward stay valid; ``reset`` drops the
+    current chunk so that an iteration (and a captured graph of it) starts with a fresh draw."""
+
+    CHUNK = 1 << 17
+
+    def __init__(self):
+        self._chunks = {}
+
+    def reset(self):
+        self._chunks.clear()
+
+    def take(self, n, base, device):
+        key = (str(device), float(base))
+        ent = self._chunks.get(key)
+        n4 = (n + 3) & ~3
+        if ent is None or ent[1] + n4 > ent[0].numel():
+            normal = torch.randn(max(self.CHUNK, n4), device=device, dtype=torch.float32)
+            ent = self._chunks[key] = [ops.pow_base_raw(normal, base), 0]
+        out = ent[0][ent[1]:ent[1] + n]
+        ent[1] += n4
+        return out
+
+
+_drop_pool = _DropPool()
+
+
+def drop_pool_reset() -> None:
+    _drop_pool.reset()
+
+
 class PixelNorm(nn.Module):
     def forward(self, x):
         return pixel_norm(x)
@@ -68,8 +101,7 @@ class GDropLayer(nn.Module):
         if _drop_mode == "numpy":
             rnd = (1 + self.strength) ** np.random.normal(size=[batch, channels, 1])
             return torch.from_numpy(rnd.astype(np.float32).reshape(batch, channels)).to(device)
-        n = torch.randn((batch, channels), device=device, dtype=torch.float32)
-        return ops.pow_base_raw(n, 1.0 + self.strength)
+        return _drop_pool.take(batch * channels, 1.0 + self.strength, device).view(batch, channels)
 
     def forward(self, x, deterministic=False):
         if deterministic or not self.strength:

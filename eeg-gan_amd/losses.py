@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 from torch.autograd import grad
 
-from . import ops
+from . import layers, ops
 from .utils import cudize
 
 one = None
@@ -66,6 +66,7 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
         raise NotImplementedError(f"loss_type={loss_type!r}: only the wgan family is supported")
     if random_multiply or feature_matching_lambda != 0.0:
         raise NotImplementedError("random_multiply / feature matching are not supported")
+    layers.drop_pool_reset()
     gen.zero_grad()
     g_, _ = gen(z)
     with (_frozen(dis) if skip_dis_weight_grads else contextlib.nullcontext()):
@@ -82,6 +83,7 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
         raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
+    layers.drop_pool_reset()
     dis.zero_grad()
     d_real, _, _ = dis(real)
     with torch.no_grad():

@@ -534,6 +534,12 @@ def axpby(a, ca, b, cb):
 
 
 # --------------------------------------------------------------------------------------- minibatch stddev
+def _mbstd_ws(x, group):
+    B, Cc, T = x.shape
+    nbytes = _lib.load().eeggan_mbstd_workspace(B, Cc, T, group)
+    return torch.empty(max(nbytes, 4), device=x.device, dtype=torch.uint8)
+
+
 class _MbStdBwd(Function):
     @staticmethod
     def forward(ctx, x, gout, group):
@@ -553,8 +559,9 @@ class _MbStdBwd(Function):
         B, Cc, T = x.shape
         ggout = torch.empty_like(gout)
         gx2 = torch.empty_like(x)
+        ws = _mbstd_ws(x, ctx.group)
         call("eeggan_mbstd_bwd_bwd", x.data_ptr(), gout.data_ptr(), q.data_ptr(), ggout.data_ptr(), gx2.data_ptr(),
-             B, Cc, T, ctx.group, _stream())
+             ws.data_ptr(), B, Cc, T, ctx.group, _stream())
         return gx2, ggout, None
 
 
@@ -564,7 +571,8 @@ class _MbStd(Function):
         x = _chk(x, "mbstd x")
         B, Cc, T = x.shape
         out = torch.empty((B, Cc + 1, T), device=x.device, dtype=torch.float32)
-        call("eeggan_mbstd_fwd", x.data_ptr(), out.data_ptr(), B, Cc, T, group, _stream())
+        ws = _mbstd_ws(x, group)
+        call("eeggan_mbstd_fwd", x.data_ptr(), out.data_ptr(), ws.data_ptr(), B, Cc, T, group, _stream())
         ctx.save_for_backward(x)
         ctx.group = group
         return out

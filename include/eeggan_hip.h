@@ -131,11 +131,14 @@ int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float
  * bwd: gx = gout[:, :C] + d(out[:,C])/dx^T gout[:, C]
  * bwd_bwd: given q = cotangent of gx:  ggout[B, C+1, T] and gx2[B, C, T] (the derivative of
  *      bwd w.r.t. gout and w.r.t. x). */
-int eeggan_mbstd_fwd(const float* x, float* out, int B, int C, int T, int group, void* stream);
+/* fwd and bwd_bwd need eeggan_mbstd_workspace(...) bytes of device scratch (partial sums). */
+size_t eeggan_mbstd_workspace(int B, int C, int T, int group);
+int eeggan_mbstd_fwd(const float* x, float* out, void* workspace, int B, int C, int T, int group,
+                     void* stream);
 int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
                      void* stream);
 int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
-                         int B, int C, int T, int group, void* stream);
+                         void* workspace, int B, int C, int T, int group, void* stream);
 
 /* ---- WGAN-GP loss (losses.py:94-100,114-119 and 47-48) -----------------------------------
  * loss = mean(d_fake) - mean(d_real) + drift*mean(d_real^2) + lambda/target^2 * mean((|g_b|_2 - target)^2)
