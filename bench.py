@@ -78,7 +78,7 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False):
         model_depth, alpha = depth, 1.0
 
     d_loss, g_loss = config.loss_closures()
-    cls = Trainer if (eager or world > 1 or layers.get_drop_mode() != "device") else GraphedTrainer
+    cls = Trainer if (eager or layers.get_drop_mode() != "device") else GraphedTrainer
     tr = cls(d, g, d_loss, g_loss, _DS(), latents(), 0, opt_g, opt_d)
     tr.dataiter = reals()
     tr.grad_sync = DataParallelStep() if world > 1 else None
@@ -161,6 +161,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    try:
+        tr.train()  # not timed, not counted: the first call captures the graphs
+    except Exception as exc:  # noqa: BLE001 -- any capture failure: same kernels, launched one by one
+        if args.eager:
+            raise
+        print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank, eager=True)
     for _ in range(args.warmup):
         tr.train()
     barrier()

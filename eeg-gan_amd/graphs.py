@@ -77,45 +77,66 @@ class GraphedTrainer(Trainer):
     runs needed for capture are undone (parameters and optimizer state are restored), so the
     sequence of updates equals the eager trainer's.  While alpha < 1 (fade-in) alpha changes at
     every iteration and is a kernel argument, so those iterations run eagerly.  Requires the
-    device noise mode (``layers.set_drop_mode('device')``): host RNG draws cannot be captured."""
+    device noise mode (``layers.set_drop_mode('device')``): host RNG draws cannot be captured.
+
+    With a data-parallel ``grad_sync`` (``parallel.DataParallelStep``) every iteration is two
+    graphs -- forward + backward + gradient-bucket pack, and the Adam step reading the bucket --
+    with the gradient all-reduce issued eagerly between the two replays."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._key = None
-        self._d_call: Optional[GraphedCall] = None
-        self._g_call: Optional[GraphedCall] = None
+        self._d_parts = None
+        self._g_parts = None
         self._real: Optional[torch.Tensor] = None
         self._z: Optional[torch.Tensor] = None
 
     def _capture(self, real, z, key):
         if layers.get_drop_mode() != "device":
             raise RuntimeError("GraphedTrainer needs layers.set_drop_mode('device')")
-        if self.grad_sync is not None:
-            raise NotImplementedError("graph capture of the data-parallel step is not supported yet")
+        sync = self.grad_sync
+        if sync is not None and not (hasattr(sync, "pack") and hasattr(sync, "reduce") and hasattr(sync, "apply")):
+            raise NotImplementedError("GraphedTrainer: grad_sync must offer pack/reduce/apply phases")
+        bucketed = sync is not None and getattr(sync, "bucketed", True)
         self._real, self._z = real.clone(), z.clone()
         snap = _snapshot([self.discriminator, self.generator], [self.optimizer_d, self.optimizer_g])
 
-        def d_iter():
-            loss = self.d_loss(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
-            loss.backward()
-            self.optimizer_d.step()
-            return loss.detach()
+        def iteration(loss_fn, module, optimizer):
+            """(graph of forward + backward [+ bucket pack], bucket, graph of the optimizer step)."""
+            box = {}
 
-        def g_iter():
-            loss = self.g_loss(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
-            loss.backward()
-            self.optimizer_g.step()
-            return loss.detach()
+            def fwd_bwd():
+                loss = loss_fn(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
+                loss.backward()
+                if bucketed:
+                    box["bucket"] = sync.pack(module)
+                else:
+                    optimizer.step()
+                return loss.detach()
 
-        self._d_call = GraphedCall(d_iter)
-        self._g_call = GraphedCall(g_iter)
+            first = GraphedCall(fwd_bwd)
+            if not bucketed:
+                return first, None, None
+            bucket = box["bucket"]
+            return first, bucket, GraphedCall(lambda: sync.apply(optimizer, bucket))
+
+        self._d_parts = iteration(self.d_loss, self.discriminator, self.optimizer_d)
+        self._g_parts = iteration(self.g_loss, self.generator, self.optimizer_g)
         _restore(snap)
         self._key = key
 
+    def _replay(self, parts):
+        first, bucket, second = parts
+        loss = first()
+        if bucket is not None:
+            # the collective runs between two replays, never inside a captured region
+            self.grad_sync.reduce(bucket)
+            second()
+        return loss
+
     def train(self):
         gen, dis = self.generator, self.discriminator
-        if gen.alpha != 1.0 or self.grad_sync is not None or self.lr_scheduler_d is not None \
-                or self.lr_scheduler_g is not None:
+        if gen.alpha != 1.0 or self.lr_scheduler_d is not None or self.lr_scheduler_g is not None:
             self._key = None
             return super().train()
         z = cudize(next(self.random_latents_generator))["z"]
@@ -129,9 +150,9 @@ class GraphedTrainer(Trainer):
             self.cur_nimg += real.size(0)
             self._real.copy_(real)
             self._z.copy_(z)
-            d_loss = self._d_call()
+            d_loss = self._replay(self._d_parts)
             z = cudize(next(self.random_latents_generator))["z"]
         self._z.copy_(z)
-        g_loss = self._g_call()
+        g_loss = self._replay(self._g_parts)
         self.iterations += 1
         self.call_plugins("iteration", self.iterations, *(g_loss, d_loss))

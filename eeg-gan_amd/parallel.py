@@ -62,23 +62,40 @@ class GradBucket:
 
 class DataParallelStep:
     """Callable installed as ``Trainer.grad_sync``: pack -> all-reduce(sum) -> Adam reading the
-    bucket with grad_scale = 1/world.  With ``world == 1`` (or no process group) it only steps."""
+    bucket with grad_scale = 1/world.  With ``world == 1`` (or no process group) it only steps,
+    unless ``always_bucket`` asks for the full pack/reduce/apply sequence (used by tests).
 
-    def __init__(self, process_group=None):
+    The three phases are also exposed one by one (``pack``, ``reduce``, ``apply``) so that a graph
+    trainer can capture ``pack`` with the backward and ``apply`` on its own, and issue the
+    collective between the two replays, outside any capture."""
+
+    def __init__(self, process_group=None, always_bucket: bool = False):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.bucketed = self.world > 1 or always_bucket
         self.buckets: Dict[int, GradBucket] = {}
 
-    def __call__(self, module: torch.nn.Module, optimizer):
-        if self.world == 1:
-            optimizer.step()
-            return
+    def pack(self, module: torch.nn.Module) -> GradBucket:
         params = [p for p in module.parameters() if p.grad is not None]
         bucket = self.buckets.get(id(module))
         if bucket is None or bucket.key() != tuple(id(p) for p in params):
             bucket = GradBucket(params)
             self.buckets[id(module)] = bucket
         bucket.pack()
-        dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+        return bucket
+
+    def reduce(self, bucket: GradBucket) -> None:
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def apply(self, optimizer, bucket: GradBucket) -> None:
         optimizer.grad_scale = 1.0 / self.world
         optimizer.step(grads=bucket.views)
+
+    def __call__(self, module: torch.nn.Module, optimizer):
+        if not self.bucketed:
+            optimizer.step()
+            return
+        bucket = self.pack(module)
+        self.reduce(bucket)
+        self.apply(optimizer, bucket)

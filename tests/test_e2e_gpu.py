@@ -243,49 +243,116 @@ def test_full_step_fixture(dev):
             assert e < tol, f"{net}.{k}: update differs by {e:.3e} (tolerance {tol:.3e})"
 
 
-def test_graph_replay_equals_eager(dev):
-    """Two training steps through captured HIP graphs move the weights exactly like eager launches
-    (noise off and fixed mixing factors, so that both runs see the same random inputs)."""
-    from eeggan_amd import config, layers
-    from eeggan_amd.graphs import GraphedTrainer
+def _two_steps(dev, cls, sync_factory=None, lr=0.002):
+    """Two training steps at depth 2 with the noise off and fixed mixing factors (so that every
+    variant sees the same random inputs).  Returns the weights, Adam's moments and step counts."""
+    from eeggan_amd import config
     from eeggan_amd.layers import GDropLayer
     from eeggan_amd.optim import Adam
-    from eeggan_amd.trainer import Trainer
     depth, B = 2, 8
     T = config.seq_len(depth)
     gen = torch.Generator().manual_seed(4)
     reals = [torch.randn(B, 5, T, generator=gen).to(dev) for _ in range(10)]
     zs = [torch.randn(B, 256, generator=gen).to(dev) for _ in range(12)]
     mix = torch.rand(B, 1, 1, generator=gen).to(dev)
-    results = []
+    g, d = config.build_models(9)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    for m in list(g.modules()) + list(d.modules()):
+        if isinstance(m, GDropLayer):
+            m.strength = 0
+    opt_g = Adam(g.parameters(), lr, **config.ADAM)
+    opt_d = Adam(d.parameters(), lr, **config.ADAM)
+    d_loss_fn, g_loss_fn = config.loss_closures()
+
+    class _DS:
+        model_depth, alpha = depth, 1.0
+
+    tr = cls(d, g, lambda dis, ge, r, z: d_loss_fn(dis, ge, r, z, mixing=mix), g_loss_fn, _DS(),
+             iter([{"z": z} for z in zs]), 0, opt_g, opt_d)
+    tr.dataiter = iter([{"x": r} for r in reals])
+    if sync_factory is not None:
+        tr.grad_sync = sync_factory()
+    tr.train()
+    tr.train()
+    torch.cuda.synchronize()
+    out = {}
+    for tag, net, opt in (("G", g, opt_g), ("D", d, opt_d)):
+        for k, p in net.named_parameters():
+            out[f"{tag}.{k}"] = p.detach().clone()
+            if p in opt.state:
+                st = opt.state[p]
+                out[f"{tag}.{k}.m"], out[f"{tag}.{k}.v"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+                out[f"{tag}.{k}.step"] = st["step"].clone()
+    return out
+
+
+def _same_trajectory(base, other, what):
+    """The accumulation order of the three gradient contributions of a critic weight is up to the
+    autograd engine (nodes made during the double backward are numbered by another thread), so two
+    runs of the same eager code already differ by an ulp in some gradients, and Adam with beta1 = 0
+    turns an ulp around zero into a full +-lr step.  Hence two comparisons:
+
+    * with lr = 0 the weights stay put and every iteration is independent of that noise: Adam's
+      moments (exp_avg = the last gradient, exp_avg_sq = the decayed sum of squares over all
+      iterations) must agree to 1e-5 of the tensor's scale and the step counts exactly;
+    * with lr > 0 all but a small fraction of the weight elements must agree to 1e-6."""
+    frozen_a, live_a = base
+    frozen_b, live_b = other
+    assert frozen_a.keys() == frozen_b.keys() and live_a.keys() == live_b.keys()
+    for k, a in frozen_a.items():
+        b = frozen_b[k]
+        if k.endswith(".step") or not k.endswith((".m", ".v")):
+            assert torch.equal(a, b), f"{what}: {k} differs with lr = 0"
+        else:
+            err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-30)
+            assert err < 1e-5, f"{what}: {k} differs by {err:.2e} of its scale with lr = 0"
+    moved = 0
+    for k, a in live_a.items():
+        if k.endswith((".m", ".v", ".step")):
+            continue
+        bad = float(((a - live_b[k]).abs() > 1e-6).float().mean())
+        assert bad < 0.02, f"{what}: {100 * bad:.2f}% of {k} differs after two steps"
+        moved += 1
+    assert moved > 0
+
+
+def test_graph_replay_equals_eager(dev):
+    """Two training steps through captured HIP graphs follow the eager trajectory."""
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
     layers.set_drop_mode("device")
     try:
-        for cls in (Trainer, GraphedTrainer):
-            g, d = config.build_models(9)
-            g, d = g.to(dev), d.to(dev)
-            g.depth = d.depth = depth
-            for m in list(g.modules()) + list(d.modules()):
-                if isinstance(m, GDropLayer):
-                    m.strength = 0
-            opt_g = Adam(g.parameters(), 0.002, **config.ADAM)
-            opt_d = Adam(d.parameters(), 0.002, **config.ADAM)
-            d_loss_fn, g_loss_fn = config.loss_closures()
-
-            class _DS:
-                model_depth, alpha = depth, 1.0
-
-            tr = cls(d, g, lambda dis, ge, r, z: d_loss_fn(dis, ge, r, z, mixing=mix), g_loss_fn, _DS(),
-                     iter([{"z": z} for z in zs]), 0, opt_g, opt_d)
-            tr.dataiter = iter([{"x": r} for r in reals])
-            tr.train()
-            tr.train()
-            torch.cuda.synchronize()
-            results.append(({k: v.clone() for k, v in g.state_dict().items()},
-                            {k: v.clone() for k, v in d.state_dict().items()},
-                            float(opt_d.state[next(d.parameters())]["step"]) if False else None))
+        base = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
+        graphed = _two_steps(dev, GraphedTrainer, lr=0.0), _two_steps(dev, GraphedTrainer)
     finally:
         layers.set_drop_mode("numpy")
-    (g0, d0, _), (g1, d1, _) = results
-    for a, b in ((g0, g1), (d0, d1)):
-        for k in a:
-            assert torch.equal(a[k], b[k]), f"{k} differs between eager and graph replay"
+    _same_trajectory(base, graphed, "graph replay")
+
+
+def test_data_parallel_graphs_equal_eager(dev):
+    """The data-parallel step (gradient bucket -> RCCL all-reduce -> Adam reading the bucket), eager
+    and as two captured graphs around the collective, on a one-rank RCCL group: both must follow
+    the plain single-process trainer."""
+    import torch.distributed as dist
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.parallel import DataParallelStep
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device(dev))
+    try:
+        sync = lambda: DataParallelStep(always_bucket=True)
+        base = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
+        eager = _two_steps(dev, Trainer, sync, lr=0.0), _two_steps(dev, Trainer, sync)
+        graphed = _two_steps(dev, GraphedTrainer, sync, lr=0.0), _two_steps(dev, GraphedTrainer, sync)
+    finally:
+        layers.set_drop_mode("numpy")
+        if own_group:
+            dist.destroy_process_group()
+    _same_trajectory(base, eager, "eager data-parallel step")
+    _same_trajectory(base, graphed, "graphed data-parallel step")
