@@ -1,0 +1,51 @@
+// Argument block shared by the forward/input-gradient convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace eeggan {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* drop;
+    float* y;
+    const float* mask_y;
+    const float* mask_drop;
+    float mask_slope;
+    int B, Cin, Cout, T;
+    int ST;  // 32-wide subtiles per sample = ceil(T/32)
+    int NS;  // total subtiles = B*ST
+    float in_scale;
+    int act;
+    float act_param;
+    const float* act_aux;
+    int vec;  // T % 4 == 0: 16-byte global loads are aligned
+    int wpb;    // weight-stationary kernel: waves per workgroup that take work units
+    int debug;  // timing experiments only (EEGGAN_DEBUG): 1 no MFMA, 2 no restaging, 4 no stores
+#ifdef EEGGAN_TRACE
+    unsigned long long* trace;  // [4 traced blocks][8 waves][TRACE_STEPS][8] shader-clock stamps
+#endif
+};
+
+#ifdef EEGGAN_TRACE
+constexpr int TRACE_STEPS = 16;
+#define EEGGAN_STAMP(step, k)                                                                              \
+    do {                                                                                                   \
+        if (a.trace && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 4 && (threadIdx.x & 63) == 0 &&       \
+            (step) < TRACE_STEPS)                                                                          \
+            a.trace[((((blockIdx.x >> 6) * 8 + (threadIdx.x >> 6)) * TRACE_STEPS) + (step)) * 8 + (k)] =   \
+                __builtin_amdgcn_s_memtime();                                                              \
+    } while (0)
+#else
+#define EEGGAN_STAMP(step, k) \
+    do {                      \
+    } while (0)
+#endif
+
+// Weight-stationary variant for layers with at most 64 input and 64 output channels (conv_ws.hip).
+// Returns -1 when the shape is not covered, otherwise the launch status.
+int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st);
+int num_cus();
+
+}  // namespace eeggan

@@ -16,6 +16,7 @@
 // registers are four runs of 4 consecutive time steps: 16-byte stores (4-byte-per-lane stores
 // are issue-bound on this chip and cost more than the MFMAs of a 64-channel tile).
 #include "common.h"
+#include "conv_args.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -24,26 +25,6 @@ namespace eeggan {
 namespace {
 
 constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment)
-
-struct ConvArgs {
-    const float* x;
-    const float* w;
-    const float* bias;
-    const float* drop;
-    float* y;
-    const float* mask_y;
-    const float* mask_drop;
-    float mask_slope;
-    int B, Cin, Cout, T;
-    int ST;  // 32-wide subtiles per sample = ceil(T/32)
-    int NS;  // total subtiles = B*ST
-    float in_scale;
-    int act;
-    float act_param;
-    const float* act_aux;
-    int vec;  // T % 4 == 0: 16-byte global loads are aligned
-    int debug;  // timing experiments only (EEGGAN_DEBUG): 1 no MFMA, 2 no restaging, 4 no stores
-};
 
 // ---------------------------------------------------------------------------------------
 // Global -> register -> LDS staging of ROWS channels x NT subtiles of an activation.
@@ -369,14 +350,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    EEGGAN_STAMP(0, 6);
     setup_tile(p_tile);
     prefetch();
     commit(smem);
     __syncthreads();
+    EEGGAN_STAMP(0, 7);
 
     int c_tile = blockIdx.x, c_chunk = 0;  // step being computed
     for (int step = 0; step < nsteps; ++step) {
         const bool more = step + 1 < nsteps;
+        EEGGAN_STAMP(step, 0);
         if (more) {
             if (++p_chunk == nchunks) {
                 p_chunk = 0;
@@ -386,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             if (!(a.debug & 2)) prefetch();
             __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
         }
+        EEGGAN_STAMP(step, 1);
         const float* buf = smem + (step & 1) * BUF;
         const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
         const float* Bp = buf + CT * WLD + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
@@ -410,6 +395,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[n], av[i][u], acc[i][n], 0, 0, 0);
             }
         }
+        EEGGAN_STAMP(step, 2);
         if (c_chunk + 1 == nchunks) {
             // epilogue of the finished tile: bias -> activation -> per-(sample, channel) multiplier.
             // The activation is dispatched once (wave-uniform); optional operands are read through
@@ -498,10 +484,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             ++c_chunk;
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and their consumers below it
+        EEGGAN_STAMP(step, 3);
         if (more && !(a.debug & 2)) commit(smem + ((step + 1) & 1) * BUF);
+        EEGGAN_STAMP(step, 4);
         __syncthreads();
+        EEGGAN_STAMP(step, 5);
     }
 }
+
+}  // namespace
 
 int num_cus() {
     static int cus = 0;
@@ -513,6 +504,8 @@ int num_cus() {
     }
     return cus;
 }
+
+namespace {
 
 template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
@@ -544,6 +537,11 @@ template <int K>
 int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     const long long ns = a.NS;
     auto tiles = [&](int ct, int nt) { return ((ns + nt - 1) / nt) * ((a.Cout + ct - 1) / ct); };
+    static const bool no_ws = getenv("EEGGAN_NO_WS") != nullptr;  // timing experiments only
+    if (!no_ws) {
+        const int rc = launch_conv_ws(a, K, st);
+        if (rc >= 0) return rc;
+    }
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
     if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
     if (K == 3) {
@@ -765,6 +763,7 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     a.vec = (T % 4 == 0) ? 1 : 0;
     static const int dbg = getenv("EEGGAN_DEBUG") ? atoi(getenv("EEGGAN_DEBUG")) : 0;
     a.debug = dbg;
+    a.wpb = 0;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
 }

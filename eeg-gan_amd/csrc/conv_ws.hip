@@ -1,0 +1,353 @@
+// Weight-stationary fp32 MFMA convolution for the 64-channel layers of the path (k = 3, same
+// padding, at most 64 input and 64 output channels): forward and, on flipped weights, input gradient.
+//
+// These layers carry most of the step's flops but only ~10 us of matrix work per launch, so the
+// kernel is organised to keep the matrix pipes fed rather than around a workgroup-wide pipeline:
+//   * the whole (scaled) weight matrix [64][64*K] is staged into LDS once per workgroup;
+//   * a workgroup is 8 independent waves (2 per SIMD).  A wave owns one work unit at a time -- all 64
+//     output channels of one 32-sample subtile -- with a private LDS region for its input subtile;
+//     after the initial weight staging there is no workgroup barrier, so the waves drift apart and
+//     one wave's loads, LDS traffic and stores overlap the other wave's MFMAs on the same SIMD;
+//   * the next unit's input is loaded global -> registers before the MFMA block and written to LDS
+//     after the epilogue;
+//   * the epilogue transposes the accumulators through the wave's LDS region so that every global
+//     store instruction writes eight full 128-byte lines (bias, activation and the per-(sample,
+//     channel) multiplier are applied on the way).
+#include "common.h"
+#include "conv_args.h"
+
+#include <type_traits>
+
+namespace eeggan {
+namespace {
+
+constexpr int WS_WAVES = 8;
+constexpr int XL = 40;                   // LDS floats per input row: [3 unused][halo][32 samples][halo][3 unused]
+constexpr int XHALF = 32 * XL + 32;      // rows 32..63 start here; the extra 32 floats put the two lane
+                                         // halves of an operand read on disjoint LDS banks
+constexpr int XREG = XHALF + 32 * XL;    // floats per wave region (2592)
+constexpr int EL = 36;                   // row stride of the transposed output tile, which reuses the region
+static_assert(64 * EL <= XREG, "output tile must fit the wave's region");
+
+__device__ __forceinline__ int xrow(int row) { return row * XL + (row >= 32 ? 32 : 0); }
+
+// K taps; MASKED: the input is multiplied by a saved LeakyReLU/GDrop mask while it is staged;
+// FULL: Cin == Cout == 64 and T % 32 == 0, so no load or store needs a predicate.
+template <int K, bool MASKED, bool FULL>
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int KK = 64 * K;   // reduction length with the input channels padded to 64
+    constexpr int WLD = KK + 4;  // (WLD / 4) odd: conflict-free 16-byte row reads
+    constexpr int KH = KK / 2;   // k-steps: an MFMA consumes two reduction indices, one per lane half
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l31 = lane & 31;
+    const int h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* Xs = smem + 64 * WLD + wave * XREG;
+
+    // staging coordinates of this lane: 16-byte items (row r0 + 8 i, floats 4q..4q+3) and halo items
+    const int q = lane & 7, r0 = lane >> 3;
+    const int hside = lane & 1, hr0 = lane >> 1;
+    const int lo = r0 * a.T + 4 * q;
+    const int hlo = hr0 * a.T + (hside ? 32 : -1);
+
+    f32x4 xv[8], mv[MASKED ? 8 : 1];
+    float hv[2], mh[MASKED ? 2 : 1], md[MASKED ? 8 : 1], mdh[MASKED ? 2 : 1];
+
+    // The waves of a workgroup take CONSECUTIVE subtiles: their 64 input rows then share pages (and
+    // cache lines for the halos), which matters because every row of a unit lies in a different page.
+    // A small layer uses fewer waves per workgroup (a.wpb) so that it still touches every CU.
+    const int ustride = a.wpb * (int)gridDim.x;
+    int u = (int)blockIdx.x * a.wpb + wave;
+
+    // Staging state of a unit: its base pointers and the validity of this lane's items.
+    struct Unit {
+        const float* xb;
+        const float* mb;
+        int b, t0;
+        bool t_ok, h_ok;
+    };
+    auto locate = [&](int unit) {
+        Unit r;
+        r.b = unit / a.ST;
+        r.t0 = (unit - r.b * a.ST) * 32;
+        r.xb = a.x + ((long long)r.b * a.Cin) * a.T + r.t0;
+        r.mb = MASKED ? a.mask_y + ((long long)r.b * a.Cin) * a.T + r.t0 : nullptr;
+        r.t_ok = FULL || r.t0 + 4 * q < a.T;
+        r.h_ok = hside ? (r.t0 + 32 < a.T) : (r.t0 > 0);
+        return r;
+    };
+
+    // The 64 input rows are staged in four chunks; chunk c holds rows [8c, 8c+8) and [32+8c, 32+8c+8),
+    // exactly the rows the k-steps [8cK, 8(c+1)K) read (lane half 0 / half 1), so the MFMAs of chunk c
+    // can start as soon as items c and c+4 of this lane have arrived.  Chunk 0 also carries the halos.
+    // issue_chunk only issues loads; their consumers live in commit_chunk.
+    auto issue_chunk = [&](const Unit& un, int c) {
+        if (c == 0 && K > 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = hr0 + 32 * i;
+                const bool ok = un.h_ok && (FULL || row < a.Cin);
+                const int off = hlo + 32 * i * a.T;
+                hv[i] = *(ok ? un.xb + off : a.x);
+                if (MASKED) {
+                    mh[MASKED ? i : 0] = *(ok ? un.mb + off : a.mask_y);
+                    mdh[MASKED ? i : 0] = a.mask_drop ? a.mask_drop[ok ? un.b * a.Cin + row : 0] : 1.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = c + 4 * k;
+            const int row = r0 + 8 * i;
+            const bool ok = FULL || (un.t_ok && row < a.Cin);
+            const int off = lo + 8 * i * a.T;
+            xv[i] = *reinterpret_cast<const f32x4*>(ok ? un.xb + off : a.x);
+            if (MASKED) {
+                mv[MASKED ? i : 0] = *reinterpret_cast<const f32x4*>(ok ? un.mb + off : a.mask_y);
+                md[MASKED ? i : 0] = a.mask_drop ? a.mask_drop[ok ? un.b * a.Cin + row : 0] : 1.f;
+            }
+        }
+    };
+
+    // registers -> this wave's LDS region
+    auto commit_chunk = [&](const Unit& un, int c) {
+        if (c == 0 && K > 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = hr0 + 32 * i;
+                float v = hv[i];
+                if (MASKED) v *= mh[MASKED ? i : 0] > 0.f ? mdh[MASKED ? i : 0] : mdh[MASKED ? i : 0] * a.mask_slope;
+                const bool ok = un.h_ok && (FULL || row < a.Cin);
+                Xs[xrow(row) + (hside ? 36 : 3)] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = c + 4 * k;
+            const int row = r0 + 8 * i;
+            f32x4 v = xv[i];
+            if (MASKED) {
+                const f32x4 my = mv[MASKED ? i : 0];
+                const float d = md[MASKED ? i : 0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? d : d * a.mask_slope;
+            }
+            if (!FULL) {
+                const bool ok = un.t_ok && row < a.Cin;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(Xs + xrow(row) + 4 + 4 * q) = v;
+        }
+    };
+
+    EEGGAN_STAMP(0, 6);
+    // weights -> LDS, scaled, zero-padded to 64 x 64*K (once per workgroup).  Their loads are issued
+    // BEFORE the first unit's input loads: a wave's loads return in order, and the weights (served by
+    // L2 after the first workgroup) must not queue behind 8 KiB of input coming from HBM.
+    constexpr int Q4 = KK / 4;
+    constexpr int WV = 64 * Q4 / 512;
+    f32x4 wv[FULL ? WV : 1];
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int e4 = tid + 512 * i;
+            const int co = e4 / Q4, q4 = e4 - co * Q4;
+            wv[FULL ? i : 0] = *reinterpret_cast<const f32x4*>(a.w + (long long)co * KK + 4 * q4);
+        }
+    }
+    // (a wave without a unit loads unit 0 and drops it: a load inside a branch would make every later
+    // wait count conservative, i.e. the weight staging below would wait for the input as well)
+    EEGGAN_STAMP(15, 0);
+    const bool active = wave < a.wpb && u < a.NS;
+    Unit cur = locate(active ? u : 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) issue_chunk(cur, c);
+    __builtin_amdgcn_sched_barrier(0);
+    EEGGAN_STAMP(15, 1);
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int e4 = tid + 512 * i;
+            const int co = e4 / Q4, q4 = e4 - co * Q4;
+            f32x4 v = wv[FULL ? i : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
+            *reinterpret_cast<f32x4*>(Ws + co * WLD + 4 * q4) = v;
+        }
+    } else {
+        for (int idx = tid; idx < 64 * KK; idx += 512) {
+            const int co = idx / KK, r = idx - co * KK;
+            const int ci = r / K, j = r - ci * K;
+            const bool ok = co < a.Cout && ci < a.Cin;
+            const float v = a.w[ok ? ((long long)co * a.Cin + ci) * K + j : 0];
+            Ws[co * WLD + r] = ok ? v * a.in_scale : 0.f;
+        }
+    }
+    EEGGAN_STAMP(15, 2);
+    __syncthreads();  // the only workgroup barrier
+    EEGGAN_STAMP(15, 3);
+    if (!active) return;
+
+    // epilogue coordinates: this lane handles rows r0 + 8 i (output channels), floats 4q..4q+3
+    // Optional operands are read through an always-valid pointer and neutralised by a select at
+    // their use: a conditional load ends in a register copy that waits for ALL outstanding loads.
+    const bool has_bias = a.bias != nullptr, has_drop = a.drop != nullptr;
+    const float* bias_p = has_bias ? a.bias : a.w;
+    const float* drop_p = has_drop ? a.drop : a.w;
+    const int ylo = r0 * a.T + 4 * q;
+
+    const float* Ap = Ws + l31 * WLD + h * KH;
+    const float* Bp = Xs + (h ? XHALF : 0) + (4 - PAD) + l31;
+    EEGGAN_STAMP(0, 7);
+    int step = 0;
+    (void)step;
+
+    // One unit: stage its chunks, multiply, store.  MORE: another unit follows, whose chunks are
+    // loaded into the registers as they become free (the last unit is a separate instantiation rather
+    // than a branch around the loads, again to keep the wait counts exact).
+    auto unit_body = [&](auto more_tag, const Unit& nxt) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        EEGGAN_STAMP(step, 0);
+        const bool st_ok = cur.t_ok;
+        float bb[8], dd[8];  // (loaded per unit: hoisted out of the loop, their selects would wait for the input)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (FULL || r0 + 8 * i < a.Cout) ? r0 + 8 * i : 0;
+            bb[i] = bias_p[row];
+            dd[i] = drop_p[has_drop ? cur.b * a.Cout + row : 0];
+        }
+        EEGGAN_STAMP(step, 1);
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            commit_chunk(cur, c);
+            if (MORE) issue_chunk(nxt, c);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = c * (2 * K); s4 < (c + 1) * (2 * K); ++s4) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap + 4 * s4);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * WLD + 4 * s4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int s = 4 * s4 + e;
+                    const int cl = s / K, j = s - cl * K;
+                    const float bv = Bp[cl * XL + j];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a1[e], acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        EEGGAN_STAMP(step, 2);
+
+        // accumulators (lane = output channel, register r = time (r&3) + 8 (r>>2) + 4h) -> LDS tile
+        // E[channel][time]; LDS executes a wave's operations in order, so no wait is needed between
+        // the operand reads above, these writes and the reads below.
+        float* E = Xs;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v0[e] = acc0[4 * qq + e];
+                v1[e] = acc1[4 * qq + e];
+            }
+            *reinterpret_cast<f32x4*>(E + l31 * EL + 8 * qq + 4 * h) = v0;
+            *reinterpret_cast<f32x4*>(E + (32 + l31) * EL + 8 * qq + 4 * h) = v1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        float* yb = a.y + ((long long)cur.b * a.Cout) * a.T + cur.t0;
+        const float* ab = a.act_aux ? a.act_aux + ((long long)cur.b * a.Cout) * a.T + cur.t0 : a.x;
+        auto run = [&](auto tag) {
+            constexpr int ACT = decltype(tag)::value;
+            f32x4 m[ACT == EEGGAN_ACT_MASK ? 8 : 1];
+            if (ACT == EEGGAN_ACT_MASK) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = st_ok && (FULL || r0 + 8 * i < a.Cout);
+                    m[ACT == EEGGAN_ACT_MASK ? i : 0] =
+                        *reinterpret_cast<const f32x4*>(ok ? ab + ylo + 8 * i * a.T : a.act_aux);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = r0 + 8 * i;
+                f32x4 v = *reinterpret_cast<const f32x4*>(E + row * EL + 4 * q);
+                const float bias_v = has_bias ? bb[i] : 0.f;
+                const float drop_v = has_drop ? dd[i] : 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e] + bias_v;
+                    if (ACT == EEGGAN_ACT_LRELU) t = t > 0.f ? t : t * a.act_param;
+                    if (ACT == EEGGAN_ACT_TANH) t = tanhf(t * a.act_param);
+                    if (ACT == EEGGAN_ACT_MASK) t = m[ACT == EEGGAN_ACT_MASK ? i : 0][e] > 0.f ? t : t * a.act_param;
+                    v[e] = t * drop_v;
+                }
+                if (FULL || (st_ok && row < a.Cout)) *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
+            }
+        };
+        switch (a.act) {
+            case EEGGAN_ACT_LRELU: run(std::integral_constant<int, EEGGAN_ACT_LRELU>{}); break;
+            case EEGGAN_ACT_TANH: run(std::integral_constant<int, EEGGAN_ACT_TANH>{}); break;
+            case EEGGAN_ACT_MASK: run(std::integral_constant<int, EEGGAN_ACT_MASK>{}); break;
+            default: run(std::integral_constant<int, EEGGAN_ACT_NONE>{}); break;
+        }
+        EEGGAN_STAMP(step, 3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int nu = u + ustride; nu < a.NS; nu += ustride, ++step) {
+        const Unit nxt = locate(nu);
+        unit_body(std::true_type{}, nxt);
+        cur = nxt;
+    }
+    unit_body(std::false_type{}, cur);
+}
+
+template <int K, bool MASKED, bool FULL>
+int launch(const ConvArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(64 * (64 * K + 4) + WS_WAVES * XREG) * sizeof(float);
+    auto kernel = &conv_ws_kernel<K, MASKED, FULL>;
+    static bool ready = false;  // opt in to > 64 KiB of dynamic LDS (once)
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("conv1d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            return 1;
+        }
+        ready = true;
+    }
+    ConvArgs b = a;
+    b.wpb = (a.NS + num_cus() - 1) / num_cus();
+    if (b.wpb > WS_WAVES) b.wpb = WS_WAVES;
+    long long grid = (a.NS + b.wpb - 1) / b.wpb;
+    if (grid > num_cus()) grid = num_cus();
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, st, b);
+    return check_launch("conv1d");
+}
+
+}  // namespace
+
+int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st) {
+    if (K != 3 || a.Cin > 64 || a.Cout > 64 || a.Cout <= 32 || a.T % 4 != 0 || a.NS < 256) return -1;
+    if ((long long)a.Cin * a.T * 2 >= (1ll << 31) || (long long)a.Cout * a.T * 2 >= (1ll << 31)) return -1;
+    const bool full = a.Cin == 64 && a.Cout == 64 && a.T % 32 == 0;
+    if (a.mask_y) return full ? launch<3, true, true>(a, st) : launch<3, true, false>(a, st);
+    return full ? launch<3, false, true>(a, st) : launch<3, false, false>(a, st);
+}
+
+}  // namespace eeggan
