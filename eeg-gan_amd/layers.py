@@ -35,6 +35,28 @@ def get_drop_mode() -> str:
     return _drop_mode
 
 
+_segments = 1
+
+
+class batch_segments:
+    """Context manager: inside it the batch given to the networks is a concatenation of ``n`` independent
+    minibatches (e.g. reals and fakes stacked into one critic pass).  Only MinibatchStddev couples
+    samples of a batch, so only it needs to know (reference layers.py:67-90 groups within ONE minibatch)."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _segments
+        self.prev, _segments = _segments, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _segments
+        _segments = self.prev
+        return False
+
+
 class _DropPool:
     """Device-mode multipliers are drawn CHUNK values at a time (one normal draw + one power kernel)
     and handed out as slices, instead of two tiny launches per layer and pass.  A chunk is never
@@ -122,7 +144,8 @@ class MinibatchStddev(nn.Module):
             return x
         if x.shape[2] > self.stride_size:
             raise NotImplementedError("MinibatchStddev: more than one temporal window is not supported")
-        return ops.minibatch_stddev(x, int(min(x.shape[0], self.group_size)))
+        per_segment = x.shape[0] // _segments
+        return ops.minibatch_stddev(x, int(min(per_segment, self.group_size)), _segments)
 
 
 def _unsupported(name):

@@ -76,21 +76,38 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
 
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
                        iwass_drift_epsilon: float, grad_lambda: float, iwass_target: float,
-                       mixing: Optional[torch.Tensor] = None):
+                       mixing: Optional[torch.Tensor] = None, stack_real_fake: Optional[bool] = None):
     """WGAN-GP critic loss.  ``mixing`` optionally supplies the per-sample interpolation factors
-    [B, 1, 1] (otherwise drawn like the reference does); used by parity tests."""
+    [B, 1, 1] (otherwise drawn like the reference does); used by parity tests.  ``stack_real_fake``:
+    evaluate reals and fakes in one stacked critic pass (default: when GDrop noise is drawn on the device)."""
     if loss_type != "wgan_gp":
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
         raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
     layers.drop_pool_reset()
     dis.zero_grad()
-    d_real, _, _ = dis(real)
-    with torch.no_grad():
-        g_, _ = gen(z)
-    d_fake, _, _ = dis(g_)
     real_x = real["x"] if isinstance(real, dict) else real
-    fake_x = g_["x"]
+    if stack_real_fake is None:
+        stack_real_fake = layers.get_drop_mode() == "device"
+    if stack_real_fake:
+        # one critic pass over [reals; fakes]: half the launches, twice the work per launch, and one
+        # gradient contribution per weight instead of two.  The reference evaluates the two passes
+        # one after the other (losses.py:76-79); the result differs only in which GDrop draw a
+        # sample meets, so the stacked pass is used when the noise comes from the device generator
+        # and the sequential order when it follows the reference's host RNG stream.
+        with torch.no_grad():
+            g_, _ = gen(z)
+        fake_x = g_["x"]
+        n = real_x.size(0)
+        with layers.batch_segments(2):
+            scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+        d_real, d_fake = scores[:n], scores[n:]
+    else:
+        d_real, _, _ = dis(real)
+        with torch.no_grad():
+            g_, _ = gen(z)
+        d_fake, _, _ = dis(g_)
+        fake_x = g_["x"]
     alpha = get_mixing_factor(real_x.size(0)) if mixing is None else mixing
     x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
     pred_hat, _, _ = dis(x_hat)

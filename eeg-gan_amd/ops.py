@@ -534,21 +534,30 @@ def axpby(a, ca, b, cb):
 
 
 # --------------------------------------------------------------------------------------- minibatch stddev
-def _mbstd_ws(x, group):
-    B, Cc, T = x.shape
-    nbytes = _lib.load().eeggan_mbstd_workspace(B, Cc, T, group)
-    return torch.empty(max(nbytes, 4), device=x.device, dtype=torch.uint8)
+# ``segments``: the batch is a concatenation of that many independent minibatches (e.g. reals and
+# fakes stacked into one critic pass); the group statistics never mix samples of two segments, so
+# the kernels run once per segment on the corresponding slice (the batch axis is outermost).
+def _mbstd_ws(bs, Cc, T, group, device):
+    nbytes = _lib.load().eeggan_mbstd_workspace(bs, Cc, T, group)
+    return torch.empty(max(nbytes, 4), device=device, dtype=torch.uint8)
+
+
+def _seg(t, i, bs):
+    """Device address of the i-th batch segment of the contiguous tensor t."""
+    return t.data_ptr() + i * bs * (t.numel() // t.shape[0]) * 4
 
 
 class _MbStdBwd(Function):
     @staticmethod
-    def forward(ctx, x, gout, group):
+    def forward(ctx, x, gout, group, segments):
         gout = _chk(gout, "mbstd gout")
         B, Cc, T = x.shape
+        bs = B // segments
         gx = torch.empty_like(x)
-        call("eeggan_mbstd_bwd", x.data_ptr(), gout.data_ptr(), gx.data_ptr(), B, Cc, T, group, _stream())
+        for i in range(segments):
+            call("eeggan_mbstd_bwd", _seg(x, i, bs), _seg(gout, i, bs), _seg(gx, i, bs), bs, Cc, T, group, _stream())
         ctx.save_for_backward(x, gout)
-        ctx.group = group
+        ctx.group, ctx.segments = group, segments
         return gx
 
     @staticmethod
@@ -557,34 +566,40 @@ class _MbStdBwd(Function):
         x, gout = ctx.saved_tensors
         q = _chk(q, "mbstd cotangent")
         B, Cc, T = x.shape
+        bs = B // ctx.segments
         ggout = torch.empty_like(gout)
         gx2 = torch.empty_like(x)
-        ws = _mbstd_ws(x, ctx.group)
-        call("eeggan_mbstd_bwd_bwd", x.data_ptr(), gout.data_ptr(), q.data_ptr(), ggout.data_ptr(), gx2.data_ptr(),
-             ws.data_ptr(), B, Cc, T, ctx.group, _stream())
-        return gx2, ggout, None
+        for i in range(ctx.segments):
+            ws = _mbstd_ws(bs, Cc, T, ctx.group, x.device)
+            call("eeggan_mbstd_bwd_bwd", _seg(x, i, bs), _seg(gout, i, bs), _seg(q, i, bs), _seg(ggout, i, bs),
+                 _seg(gx2, i, bs), ws.data_ptr(), bs, Cc, T, ctx.group, _stream())
+        return gx2, ggout, None, None
 
 
 class _MbStd(Function):
     @staticmethod
-    def forward(ctx, x, group):
+    def forward(ctx, x, group, segments):
         x = _chk(x, "mbstd x")
         B, Cc, T = x.shape
+        if B % segments:
+            raise ValueError(f"minibatch_stddev: batch {B} is not {segments} equal segments")
+        bs = B // segments
         out = torch.empty((B, Cc + 1, T), device=x.device, dtype=torch.float32)
-        ws = _mbstd_ws(x, group)
-        call("eeggan_mbstd_fwd", x.data_ptr(), out.data_ptr(), ws.data_ptr(), B, Cc, T, group, _stream())
+        for i in range(segments):
+            ws = _mbstd_ws(bs, Cc, T, group, x.device)
+            call("eeggan_mbstd_fwd", _seg(x, i, bs), _seg(out, i, bs), ws.data_ptr(), bs, Cc, T, group, _stream())
         ctx.save_for_backward(x)
-        ctx.group = group
+        ctx.group, ctx.segments = group, segments
         return out
 
     @staticmethod
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
-        return _MbStdBwd.apply(x, gout, ctx.group), None
+        return _MbStdBwd.apply(x, gout, ctx.group, ctx.segments), None, None
 
 
-def minibatch_stddev(x, group):
-    return _MbStd.apply(x, int(group))
+def minibatch_stddev(x, group, segments=1):
+    return _MbStd.apply(x, int(group), int(segments))
 
 
 # --------------------------------------------------------------------------------------- losses

@@ -296,7 +296,9 @@ def _same_trajectory(base, other, what):
     * with lr = 0 the weights stay put and every iteration is independent of that noise: Adam's
       moments (exp_avg = the last gradient, exp_avg_sq = the decayed sum of squares over all
       iterations) must agree to 1e-5 of the tensor's scale and the step counts exactly;
-    * with lr > 0 all but a small fraction of the weight elements must agree to 1e-6."""
+    * with lr > 0 the weight DISPLACEMENTS of the two runs (weights minus the lr = 0 run's, i.e. the
+      initial weights) must agree to 5 % in norm: sign flips of a few near-zero gradient elements, and
+      what they do to later iterations, stay far below that, a missing or doubled update does not."""
     frozen_a, live_a = base
     frozen_b, live_b = other
     assert frozen_a.keys() == frozen_b.keys() and live_a.keys() == live_b.keys()
@@ -311,8 +313,12 @@ def _same_trajectory(base, other, what):
     for k, a in live_a.items():
         if k.endswith((".m", ".v", ".step")):
             continue
-        bad = float(((a - live_b[k]).abs() > 1e-6).float().mean())
-        assert bad < 0.02, f"{what}: {100 * bad:.2f}% of {k} differs after two steps"
+        da, db = a - frozen_a[k], live_b[k] - frozen_b[k]
+        if float(da.norm()) == 0.0:
+            assert float(db.norm()) == 0.0, f"{what}: {k} moved in one run only"
+            continue
+        err = float((da - db).norm()) / float(da.norm())
+        assert err < 0.05, f"{what}: displacement of {k} differs by {100 * err:.1f}% after two steps"
         moved += 1
     assert moved > 0
 
@@ -356,3 +362,46 @@ def test_data_parallel_graphs_equal_eager(dev):
             dist.destroy_process_group()
     _same_trajectory(base, eager, "eager data-parallel step")
     _same_trajectory(base, graphed, "graphed data-parallel step")
+
+
+def test_stacked_critic_pass_equals_sequential(dev):
+    """discriminator_loss with reals and fakes stacked into one critic pass (the device-noise default)
+    gives the loss and the weight gradients of the reference's two sequential passes (noise off, so
+    that both see the same multipliers).
+
+    Scores and loss agree to 1e-5.  The gradients cannot be held to that: a stacked pass runs other
+    tile shapes, so pre-activations differ in the last bit, and among ~10^6 of them a handful sit
+    close enough to zero for their LeakyReLU mask to flip, each flip changing that element's
+    gradient by 0.8 |g| (measured: 2e-3 of a gradient's norm, the same mechanism that separates the
+    reference's own fp32 and fp64 runs).  So the bar is 2e-2 of the real term's norm plus the
+    total's (the two terms nearly cancel in the total): loose for rounding, tight for a wrong
+    segment, a dropped term or a double count, which are O(1)."""
+    from eeggan_amd import config, ops
+    from eeggan_amd.layers import GDropLayer
+    depth, B = 3, 8
+    T = config.seq_len(depth)
+    gen = torch.Generator().manual_seed(11)
+    real = torch.randn(B, 5, T, generator=gen).to(dev)
+    z = torch.randn(B, 256, generator=gen).to(dev)
+    mix = torch.rand(B, 1, 1, generator=gen).to(dev)
+    g, d = config.build_models(5)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    for m in list(g.modules()) + list(d.modules()):
+        if isinstance(m, GDropLayer):
+            m.strength = 0
+    d_loss_fn, _ = config.loss_closures()
+    out = []
+    for stacked in (False, True):
+        loss = d_loss_fn(d, g, {"x": real}, {"z": z}, mixing=mix, stack_real_fake=stacked)
+        loss.backward()
+        out.append((float(loss.detach()), {k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = out
+    d.zero_grad()
+    ops.mean_scale(d({"x": real})[0], -1.0).backward()
+    term = {k: float(p.grad.norm()) for k, p in d.named_parameters() if p.grad is not None}
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
+    assert g0.keys() == g1.keys() and len(g0) > 0
+    for k in g0:
+        e = float((g0[k] - g1[k]).norm()) / max(float(g0[k].norm()) + term[k], 1e-30)
+        assert e < 2e-2, f"{k}: stacked pass differs by {e:.2e} of the real term's scale"

@@ -41,6 +41,10 @@ CONV_SHAPES = [
     (2, 64, 64, 1920, 3), (3, 64, 64, 96, 3), (2, 128, 64, 512, 3), (2, 64, 128, 512, 3), (2, 128, 128, 256, 3),
     (2, 256, 256, 128, 3), (4, 257, 256, 32, 3), (2, 256, 128, 256, 3), (2, 64, 5, 1920, 1), (2, 5, 64, 1920, 1),
     (3, 5, 256, 32, 1), (4, 256, 1, 1, 1), (2, 7, 9, 50, 3), (1, 33, 70, 37, 3), (2, 6, 10, 48, 1), (5, 20, 40, 4, 3),
+    # >= 256 subtiles of 32 samples at <= 64 channels: the weight-stationary kernel (one unit per wave,
+    # several units per wave, ragged channel counts and a ragged last subtile)
+    (8, 64, 64, 1024, 3), (34, 64, 64, 1920, 3), (9, 48, 40, 1000, 3), (16, 64, 64, 512, 3),
+    (16, 256, 256, 128, 3), (8, 256, 256, 128, 3), (16, 128, 128, 256, 3),
 ]
 
 
