@@ -683,12 +683,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
 // independent loads in flight per thread, double accumulation (the split count then does not
-// enter the rounding error), fixed order => run-to-run deterministic.
+// enter the rounding error), fixed order => run-to-run deterministic.  One launch covers the
+// weight slabs (blocks [0, nb_w)) and, behind them, the bias slabs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, long long E,
-                                                           float scale, float* __restrict__ out) {
+                                                           float scale, float* __restrict__ out, int nb_w,
+                                                           const float* __restrict__ ws_b, long long Eb,
+                                                           float* __restrict__ out_b) {
     __shared__ double part[4][64];
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + el;
+    int blk = blockIdx.x;
+    if (blk >= nb_w) {  // bias part (uniform per workgroup)
+        blk -= nb_w;
+        ws = ws_b;
+        E = Eb;
+        out = out_b;
+        scale = 1.f;
+    }
+    const long long i = (long long)blk * 64 + el;
     double acc = 0.0;
     if (i < E) {
         int k = sg;
@@ -807,13 +818,9 @@ extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, f
         hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
     if (check_launch("conv1d_wgrad")) return 1;
     const long long E = (long long)p.slab_elems;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, a.ws, p.nsplit, E,
-                       in_scale, gw);
+    const int nb_w = (int)((E + 63) / 64), nb_b = gb ? (Cout + 63) / 64 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, st, a.ws, p.nsplit, E,
+                       in_scale, gw, nb_w, a.ws_b, (long long)Cout, gb);
     if (check_launch("conv1d_wgrad reduce")) return 1;
-    if (gb) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(256), 0, st, a.ws_b,
-                           p.nsplit, (long long)Cout, 1.0f, gb);
-        if (check_launch("conv1d_wgrad bias reduce")) return 1;
-    }
     return 0;
 }

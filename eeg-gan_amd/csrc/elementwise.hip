@@ -39,16 +39,19 @@ __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __rest
 }
 
 // ---- pixel norm (+drop) ---------------------------------------------------------------------
-// Workgroup = 4 channel groups x 64 column units; a unit is 4 (VEC) or 1 time steps of one sample.
-template <bool VEC>
+// Workgroup = CG channel groups x (256 / CG) column units; a unit is W (4 or 1) time steps of one
+// sample.  The host picks (W, CG) so that even the short early stages (T = 32..256) spread over the
+// chip: fewer units per workgroup and more channel groups mean more workgroups and a shorter
+// sequential channel loop per thread.
+template <int W, int CG>
 __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ h, const float* __restrict__ drop,
                                                             float* __restrict__ y, float* __restrict__ d, int B, int C,
                                                             int T, float eps) {
-    constexpr int W = VEC ? 4 : 1;
-    __shared__ float red[4][64][W];
-    const int cg = threadIdx.x >> 6, ul = threadIdx.x & 63;
+    constexpr int UL = 256 / CG;
+    __shared__ float red[CG][UL][W];
+    const int cg = threadIdx.x / UL, ul = threadIdx.x % UL;
     const int upr = T / W;  // units per row
-    const long long unit = (long long)blockIdx.x * 64 + ul;
+    const long long unit = (long long)blockIdx.x * UL + ul;
     const bool ok = unit < (long long)B * upr;
     const int b = ok ? (int)(unit / upr) : 0;
     const int t = ok ? (int)(unit - (long long)b * upr) * W : 0;
@@ -56,9 +59,9 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
     if (ok) {
-        for (int c = cg; c < C; c += 4) {
+        for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
-            if (VEC) {
+            if (W == 4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
 #pragma unroll
                 for (int k = 0; k < W; ++k) s[k] += v[k] * v[k];
@@ -75,17 +78,19 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
     float dv[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        const float tot = (red[0][ul][k] + red[1][ul][k]) + (red[2][ul][k] + red[3][ul][k]);
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < CG; ++g) tot += red[g][ul][k];
         dv[k] = rsqrtf(tot / (float)C + eps);
     }
     if (cg == 0) {
 #pragma unroll
         for (int k = 0; k < W; ++k) d[(long long)b * T + t + k] = dv[k];
     }
-    for (int c = cg; c < C; c += 4) {
+    for (int c = cg; c < C; c += CG) {
         const long long off = ((long long)b * C + c) * T + t;
         const float r = drop ? drop[b * C + c] : 1.f;
-        if (VEC) {
+        if (W == 4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
             f32x4 o;
 #pragma unroll
@@ -97,15 +102,15 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
     }
 }
 
-template <bool VEC>
+template <int W, int CG>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const float* __restrict__ drop, const float* __restrict__ d,
                                                             float* __restrict__ gc, int B, int C, int T, float slope) {
-    constexpr int W = VEC ? 4 : 1;
-    __shared__ float red[4][64][W];
-    const int cg = threadIdx.x >> 6, ul = threadIdx.x & 63;
+    constexpr int UL = 256 / CG;
+    __shared__ float red[CG][UL][W];
+    const int cg = threadIdx.x / UL, ul = threadIdx.x % UL;
     const int upr = T / W;
-    const long long unit = (long long)blockIdx.x * 64 + ul;
+    const long long unit = (long long)blockIdx.x * UL + ul;
     const bool ok = unit < (long long)B * upr;
     const int b = ok ? (int)(unit / upr) : 0;
     const int t = ok ? (int)(unit - (long long)b * upr) * W : 0;
@@ -113,9 +118,9 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
     if (ok) {
-        for (int c = cg; c < C; c += 4) {
+        for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
-            if (VEC) {
+            if (W == 4) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
 #pragma unroll
@@ -132,14 +137,17 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
     float S[W], dv[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        S[k] = ((red[0][ul][k] + red[1][ul][k]) + (red[2][ul][k] + red[3][ul][k])) / (float)C;
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < CG; ++g) tot += red[g][ul][k];
+        S[k] = tot / (float)C;
         dv[k] = d[(long long)b * T + t + k];
     }
-    for (int c = cg; c < C; c += 4) {
+    for (int c = cg; c < C; c += CG) {
         const long long off = ((long long)b * C + c) * T + t;
         const float r = drop ? drop[b * C + c] : 1.f;
         const float ir = 1.f / r;
-        if (VEC) {
+        if (W == 4) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
             const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
             f32x4 o;
@@ -152,6 +160,18 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
             gc[off] = dv[0] * (a * r - v * ir * S[0]) * (v > 0.f ? 1.f : slope);
         }
     }
+}
+
+// (W, CG) choice: the widest accesses that still give ~one workgroup per CU.
+struct PnCfg {
+    int w, cg;
+    unsigned grid;
+};
+inline PnCfg pn_config(long long BT, bool vec) {
+    const auto blocks = [&](int w, int cg) { return (BT / w + 256 / cg - 1) / (256 / cg); };
+    if (vec && blocks(4, 4) >= 256) return {4, 4, (unsigned)blocks(4, 4)};
+    if (vec && blocks(4, 16) >= 256) return {4, 16, (unsigned)blocks(4, 16)};
+    return {1, 16, (unsigned)blocks(1, 16)};
 }
 
 // ---- small flat kernels ------------------------------------------------------------------------
@@ -240,14 +260,14 @@ extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, floa
     EEGGAN_REQUIRE(h && y && d, "pixelnorm_drop_fwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_fwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(h) && aligned16(y) && aligned16(d);
-    const long long units = (long long)B * (vec ? T / 4 : T);
-    const unsigned grid = (unsigned)((units + 63) / 64);
-    if (vec)
-        hipLaunchKernelGGL(pixelnorm_fwd_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), h, drop, y, d, B, C,
-                           T, eps);
+    const PnCfg c = pn_config((long long)B * T, vec);
+    hipStream_t st = as_stream(stream);
+    if (c.w == 4 && c.cg == 4)
+        hipLaunchKernelGGL((pixelnorm_fwd_kernel<4, 4>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
+    else if (c.w == 4)
+        hipLaunchKernelGGL((pixelnorm_fwd_kernel<4, 16>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
     else
-        hipLaunchKernelGGL(pixelnorm_fwd_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), h, drop, y, d, B,
-                           C, T, eps);
+        hipLaunchKernelGGL((pixelnorm_fwd_kernel<1, 16>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
     return check_launch("pixelnorm_drop_fwd");
 }
 
@@ -256,14 +276,17 @@ extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const 
     EEGGAN_REQUIRE(gy && y && d && gc, "pixelnorm_drop_bwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_bwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
-    const long long units = (long long)B * (vec ? T / 4 : T);
-    const unsigned grid = (unsigned)((units + 63) / 64);
-    if (vec)
-        hipLaunchKernelGGL(pixelnorm_bwd_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), gy, y, drop, d, gc,
-                           B, C, T, slope);
+    const PnCfg c = pn_config((long long)B * T, vec);
+    hipStream_t st = as_stream(stream);
+    if (c.w == 4 && c.cg == 4)
+        hipLaunchKernelGGL((pixelnorm_bwd_kernel<4, 4>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
+                           slope);
+    else if (c.w == 4)
+        hipLaunchKernelGGL((pixelnorm_bwd_kernel<4, 16>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
+                           slope);
     else
-        hipLaunchKernelGGL(pixelnorm_bwd_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), gy, y, drop, d,
-                           gc, B, C, T, slope);
+        hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 16>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
+                           slope);
     return check_launch("pixelnorm_drop_bwd");
 }
 

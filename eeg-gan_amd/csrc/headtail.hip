@@ -7,6 +7,8 @@
 // with the weight streamed coalesced and the small operand broadcast from LDS.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace eeggan {
 namespace {
 
@@ -50,6 +52,63 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                     y[((long long)b * Cout + co) * KT + (KT - 1 - tw)] = v;
                 }
             }
+        }
+    }
+}
+
+// ---- head forward on the matrix cores (KT == 32, Cin % 64 == 0) -------------------------------
+// Per output channel the layer is a [32 samples] x [Cin] x [32 taps] product whose weight operand
+// W[co][ci][tap] is already laid out as MFMA B-fragments: for a k-step (ci, ci+1) the 64 lanes read
+// 2 x 32 consecutive taps straight from global memory (two full 128-byte lines), no LDS staging.
+// grid (Cout, ceil(B/32)); the 4 waves split Cin and add their partial tiles through LDS.
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ drop, float* __restrict__ y,
+                                                            int B, int Cin, int Cout, float in_scale, int act,
+                                                            float act_param) {
+    extern __shared__ float sm[];  // zs [32][Cin + 1], then red [4][32][33]
+    const int ld = Cin + 1;
+    float* zs = sm;
+    float* red = sm + 32 * ld;
+    const int co = blockIdx.x;
+    const int b0 = blockIdx.y * 32;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int per = Cin / 4;  // input channels per wave (even)
+    // this wave's weight fragments first (the long-latency loads), then the latent tile
+    const float* wp = w + ((long long)co * Cin + wave * per + h) * 32 + l31;
+    for (int i = threadIdx.x; i < 32 * Cin; i += 256) {
+        const int bl = i / Cin, ci = i - bl * Cin;
+        zs[bl * ld + ci] = (b0 + bl < B) ? z[(long long)(b0 + bl) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* zp = zs + l31 * ld + wave * per + h;
+    for (int s0 = 0; s0 < per / 2; s0 += 8) {  // per / 2 is a multiple of 8 (Cin % 64 == 0)
+        float wf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wf[u] = wp[(long long)2 * (s0 + u) * 32];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[2 * (s0 + u)], wf[u], acc, 0, 0, 0);
+    }
+    // acc: lane column = tap, register r = sample (r&3) + 8 (r>>2) + 4h
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+    __syncthreads();
+    const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const int bl = e >> 5, tap = e & 31;
+        const int b = b0 + bl;
+        if (b < B) {
+            const float tot = (red[(0 * 32 + bl) * 33 + tap] + red[(1 * 32 + bl) * 33 + tap]) +
+                              (red[(2 * 32 + bl) * 33 + tap] + red[(3 * 32 + bl) * 33 + tap]);
+            float v = apply_act(tot * in_scale + bv, act, act_param);
+            if (drop) v *= drop[b * Cout + co];
+            y[((long long)b * Cout + co) * 32 + (31 - tap)] = v;
         }
     }
 }
@@ -298,8 +357,14 @@ extern "C" int eeggan_head_fwd(const float* z, const float* w, const float* bias
     if (check_ht("head_fwd", B, Cin, Cout, KT)) return 1;
     EEGGAN_REQUIRE(z && w && y, "head_fwd: null pointer");
     EEGGAN_REQUIRE(Cin <= 384, "head_fwd: Cin %d above the supported 384 (LDS tile)", Cin);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(Cout, (B + 31) / 32), dim3(256), (size_t)32 * Cin * sizeof(float),
-                       as_stream(stream), z, w, bias, drop, y, B, Cin, Cout, KT, in_scale, act, act_param);
+    static const bool valu_only = getenv("EEGGAN_HEAD_VALU") != nullptr;  // comparison runs only
+    if (KT == 32 && Cin % 64 == 0 && !valu_only)
+        hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3(Cout, (B + 31) / 32), dim3(256),
+                           (size_t)(32 * (Cin + 1) + 4 * 32 * 33) * sizeof(float), as_stream(stream), z, w, bias, drop,
+                           y, B, Cin, Cout, in_scale, act, act_param);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel, dim3(Cout, (B + 31) / 32), dim3(256), (size_t)32 * Cin * sizeof(float),
+                           as_stream(stream), z, w, bias, drop, y, B, Cin, Cout, KT, in_scale, act, act_param);
     return check_launch("head_fwd");
 }
 
