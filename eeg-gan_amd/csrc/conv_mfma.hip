@@ -139,8 +139,10 @@ struct XStage {
 // buffer the NEXT step reads (two LDS buffers, loads issued before the MFMA block and written
 // after it), so one barrier per step suffices and global latency hides under the MFMAs.
 //   K taps (1|3);  CK input channels per chunk;  WM x WN wave grid over (32-channel row tiles x
-//   subtiles);  VEC: T % 4 == 0.
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC>
+//   subtiles);  VEC: T % 4 == 0;  FULL: Cin % CK == 0, Cout % CT == 0 and T % 32 == 0, so that
+//   the staging needs neither predicates nor per-step address arithmetic (per-tile base pointers
+//   plus wave-uniform chunk offsets).
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
@@ -197,6 +199,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int x_b = 0, h_b = 0;
     bool x_ok = false, h_ok = false;
     int p_co0 = 0;
+    // FULL: per-tile base pointers of this thread's items
+    const float* fw[WV];
+    const float* fx = a.x;
+    const float* fh = a.x;
+    const float* fmx = a.x;
+    const float* fmh = a.x;
+    const float* fdx = a.x;
+    const float* fdh = a.x;
 
     auto setup_tile = [&](int tile) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -218,6 +228,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
             h_b = b;
             h_off = ((long long)b * a.Cin + h_row0) * a.T + t;
         }
+        if (FULL) {
+#pragma unroll
+            for (int i = 0; i < WV; ++i) fw[i] = a.w + ((long long)(p_co0 + w_row[i]) * a.Cin) * K + 4 * w_q[i];
+            x_ok = x_ok && tile < ntiles;
+            h_ok = h_ok && tile < ntiles;
+            fx = a.x + (x_ok ? x_off : 0);
+            fh = a.x + (h_ok ? h_off : 0);
+            if (a.mask_y) {
+                fmx = a.mask_y + (x_ok ? x_off : 0);
+                fmh = a.mask_y + (h_ok ? h_off : 0);
+                if (a.mask_drop) {
+                    fdx = a.mask_drop + (x_ok ? x_b * a.Cin + x_row0 : 0);
+                    fdh = a.mask_drop + (h_ok ? h_b * a.Cin + h_row0 : 0);
+                }
+            }
+        }
     };
 
     // Prefetch ONLY issues loads (from clamped, always-valid addresses) and records validity bits;
@@ -232,6 +258,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
 
     auto prefetch = [&]() {  // global -> registers for step (p_tile, p_chunk)
         const int ci0 = p_chunk * CK;
+        if (FULL) {
+            // every address = per-tile base + a wave-uniform offset; a whole-item predicate (tile tail,
+            // sample edge) only redirects the base to a valid address, its value is dropped in commit()
+            const int wo = ci0 * K;
+            const long long xo = (long long)ci0 * a.T;
+#pragma unroll
+            for (int i = 0; i < WV; ++i) wv[i] = *reinterpret_cast<const f32x4*>(fw[i] + wo);
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                const long long o = x_ok ? xo + (long long)(i * XROWS) * a.T : 0;
+                xv[i] = *reinterpret_cast<const f32x4*>(fx + o);
+                if (a.mask_y) {  // wave-uniform
+                    mv[VEC ? i : 0] = *reinterpret_cast<const f32x4*>(fmx + o);
+                    mdv[i] = a.mask_drop ? fdx[x_ok ? ci0 + i * XROWS : 0] : 1.f;
+                }
+            }
+            if (K > 1) {
+#pragma unroll
+                for (int i = 0; i < HV; ++i) {
+                    const bool ok = h_ok && h_row0 + i * HROWS < CK;
+                    const long long o = ok ? xo + (long long)(i * HROWS) * a.T : 0;
+                    hv[i] = fh[o];
+                    if (a.mask_y) {
+                        mhv[i] = fmh[o];
+                        mdh[i] = a.mask_drop ? fdh[ok ? ci0 + i * HROWS : 0] : 1.f;
+                    }
+                }
+            }
+            return;
+        }
         okbits = 0;
         if (wvec) {
 #pragma unroll
@@ -304,6 +360,37 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     auto commit = [&](float* buf) {  // registers -> LDS buffer (all consumers of the prefetch live here)
         float* Ws = buf;
         float* Xs = buf + CT * WLD;
+        if (FULL) {
+#pragma unroll
+            for (int i = 0; i < WV; ++i) {
+                f32x4 v = wv[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
+                *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < XV; ++i) {
+                f32x4 v = xv[i];
+                if (a.mask_y) {
+                    const f32x4 my = mv[VEC ? i : 0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? mdv[i] : mdv[i] * a.mask_slope;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = x_ok ? v[e] : 0.f;
+                *reinterpret_cast<f32x4*>(Xs + (x_row0 + i * XROWS) * XLD + x_n * SUB + 4 + 4 * x_q) = v;
+            }
+            if (K > 1) {
+#pragma unroll
+                for (int i = 0; i < HV; ++i) {
+                    const int row = h_row0 + i * HROWS;
+                    float u = hv[i];
+                    if (a.mask_y) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
+                    if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = h_ok ? u : 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const bool ok = (okbits >> i) & 1u;
@@ -507,10 +594,10 @@ int num_cus() {
 
 namespace {
 
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (CT * (CK * K + 4) + CK * NT * SUB) * sizeof(float);
-    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC>;
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL>;
     static int per_cu = 0;  // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once)
     if (per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -551,8 +638,10 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
         if (cfg == 2) return launch_fwd<3, 64, 4, 16, 1, 4, true>(a, st);
         if (cfg == 3) return launch_fwd<3, 64, 2, 16, 2, 2, true>(a, st);
     }
-    if (tiles(64, 4) >= num_cus()) return launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
-    return launch_fwd<K, 64, 2, 32, 2, 2, true>(a, st);
+    const bool full = a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.T % 32 == 0;
+    if (tiles(64, 4) >= num_cus())
+        return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
+    return full ? launch_fwd<K, 64, 2, 32, 2, 2, true, true>(a, st) : launch_fwd<K, 64, 2, 32, 2, 2, true>(a, st);
 }
 
 __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
