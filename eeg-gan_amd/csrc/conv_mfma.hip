@@ -675,14 +675,16 @@ struct WgradArgs {
     int vec;
 };
 
-template <int K>
+// FULL: Cin % 64 == 0, Cout % 64 == 0, T % 32 == 0 and T % 4 == 0: staging without predicates on
+// channels or time, with one wave-uniform (sample, time) decode per iteration, two LDS buffers and a
+// single barrier per iteration.  Otherwise the generic XStage path.
+template <int K, bool FULL>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NTW = 2;
     constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
+    constexpr int BUF = 2 * 64 * LD;   // floats per LDS buffer (gy tile + x tile)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;            // [64][LD]
-    float* Xs = smem + 64 * LD;  // [64][LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -703,27 +705,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
 
-    XStage<64, NTW, LD, false> gs;
-    XStage<64, NTW, LD, (K > 1)> xs;
-
     const int it0 = split * a.iters;
     const int total_pairs = (a.NS + NTW - 1) / NTW;
     int it1 = it0 + a.iters;
     if (it1 > total_pairs) it1 = total_pairs;
 
-    if (it0 < it1) {
-        gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, it0 * NTW, co0, a.vec);
-        xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, it0 * NTW, ci0, a.vec);
-    }
-    for (int it = it0; it < it1; ++it) {
-        gs.store(Gs);
-        xs.store(Xs);
-        __syncthreads();
-        if (it + 1 < it1) {
-            gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, (it + 1) * NTW, co0,
-                    a.vec);
-            xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, (it + 1) * NTW, ci0, a.vec);
-        }
+    auto mfma_block = [&](const float* Gs, const float* Xs) {
         const float* Gp = Gs + (cot * 32 + l31) * LD + 4 + 4 * h;
         const float* Xp = Xs + (cit * 32 + l31) * LD + 4 + 4 * h;
 #pragma unroll
@@ -749,7 +736,108 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], e[q + j + 1 - PAD], acc[j], 0, 0, 0);
             }
         }
+    };
+
+    if (FULL) {
+        // this thread's items: 16-byte item (row = r0 + 16 i, subtile n, floats 4q..4q+3) of both tiles,
+        // and one halo sample (row hr, subtile hn, left/right) of the x tile
+        const int q = tid & 7, n = (tid >> 3) & 1, r0 = tid >> 4;
+        const int hs = tid & 1, hn = (tid >> 1) & 1, hr = tid >> 2;
+        f32x4 gv[4], xv[4], mv[4];
+        float md[4], hv = 0.f;
+        bool ok = false, hok = false;
+
+        auto issue = [&](int it) {  // loads only; consumers live in commit()
+            // wave-uniform decode of the two subtiles of this iteration
+            int bb[2], tt[2];
+            bool vv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int sub = it * NTW + m;
+                vv[m] = sub < a.NS;
+                bb[m] = vv[m] ? sub / a.ST : 0;
+                tt[m] = vv[m] ? (sub - bb[m] * a.ST) * 32 : 0;
+            }
+            const int b = n ? bb[1] : bb[0], t0 = n ? tt[1] : tt[0];
+            ok = n ? vv[1] : vv[0];
+            const float* gp = a.gy + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q;
+            const float* xp = a.x + ((long long)b * a.Cin + ci0 + r0) * a.T + t0 + 4 * q;
+            const float* mp = a.mask_y ? a.mask_y + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q : a.gy;
+            const float* dp = a.mask_drop ? a.mask_drop + b * a.Cout + co0 + r0 : a.gy;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long o = (long long)(16 * i) * a.T;
+                gv[i] = *reinterpret_cast<const f32x4*>(gp + o);
+                xv[i] = *reinterpret_cast<const f32x4*>(xp + o);
+                if (a.mask_y) {  // wave-uniform
+                    mv[i] = *reinterpret_cast<const f32x4*>(mp + o);
+                    md[i] = dp[a.mask_drop ? 16 * i : 0];
+                }
+            }
+            if (K > 1) {
+                const int hb = hn ? bb[1] : bb[0], ht0 = hn ? tt[1] : tt[0];
+                const int t = ht0 + (hs ? 32 : -1);
+                hok = (hn ? vv[1] : vv[0]) && t >= 0 && t < a.T;
+                hv = a.x[hok ? ((long long)hb * a.Cin + ci0 + hr) * a.T + t : 0];
+            }
+        };
+        auto commit = [&](float* Gs, float* Xs) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 g = gv[i], x = xv[i];
+                if (a.mask_y) {
+                    const float d = a.mask_drop ? md[i] : 1.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] *= mv[i][e] > 0.f ? d : d * a.mask_slope;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[e] = ok ? g[e] : 0.f;
+                    x[e] = ok ? x[e] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(Gs + (r0 + 16 * i) * LD + n * SUB + 4 + 4 * q) = g;
+                *reinterpret_cast<f32x4*>(Xs + (r0 + 16 * i) * LD + n * SUB + 4 + 4 * q) = x;
+            }
+            if (K > 1) Xs[hr * LD + hn * SUB + (hs ? 36 : 3)] = hok ? hv : 0.f;
+        };
+
+        if (it0 < it1) {
+            issue(it0);
+            commit(smem, smem + 64 * LD);
+        }
         __syncthreads();
+        for (int it = it0; it < it1; ++it) {
+            const bool more = it + 1 < it1;
+            float* cur = smem + ((it - it0) & 1) * BUF;
+            float* nxt = smem + ((it - it0 + 1) & 1) * BUF;
+            if (more) issue(it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(cur, cur + 64 * LD);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) commit(nxt, nxt + 64 * LD);
+            __syncthreads();
+        }
+    } else {
+        float* Gs = smem;            // [64][LD]
+        float* Xs = smem + 64 * LD;  // [64][LD]
+        XStage<64, NTW, LD, false> gs;
+        XStage<64, NTW, LD, (K > 1)> xs;
+        if (it0 < it1) {
+            gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, it0 * NTW, co0, a.vec);
+            xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, it0 * NTW, ci0, a.vec);
+        }
+        for (int it = it0; it < it1; ++it) {
+            gs.store(Gs);
+            xs.store(Xs);
+            __syncthreads();
+            if (it + 1 < it1) {
+                gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, (it + 1) * NTW, co0,
+                        a.vec);
+                xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, (it + 1) * NTW, ci0, a.vec);
+            }
+            mfma_block(Gs, Xs);
+            __syncthreads();
+        }
     }
 
     const long long E = (long long)a.Cout * a.Cin * K;
@@ -777,7 +865,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, long long E,
                                                            float scale, float* __restrict__ out, int nb_w,
                                                            const float* __restrict__ ws_b, long long Eb,
-                                                           float* __restrict__ out_b) {
+                                                           float* __restrict__ out_b, float beta, float beta_b) {
     __shared__ double part[4][64];
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
     int blk = blockIdx.x;
@@ -787,6 +875,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         E = Eb;
         out = out_b;
         scale = 1.f;
+        beta = beta_b;
     }
     const long long i = (long long)blk * 64 + el;
     double acc = 0.0;
@@ -803,7 +892,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     part[sg][el] = acc;
     __syncthreads();
-    if (sg == 0 && i < E) out[i] = (float)(((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) * (double)scale);
+    if (sg == 0 && i < E) {
+        const float v = (float)(((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) * (double)scale);
+        out[i] = beta != 0.f ? beta * out[i] + v : v;  // beta == 0: out may hold anything (never read)
+    }
 }
 
 struct WgradPlan {
@@ -883,7 +975,8 @@ extern "C" size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T,
 
 extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
                                    int T, int K, float in_scale, const float* mask_y, const float* mask_drop,
-                                   float mask_slope, void* workspace, size_t workspace_bytes, void* stream) {
+                                   float mask_slope, float beta_w, float beta_b, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
     if (check_common(B, Cin, Cout, T, K)) return 1;
     EEGGAN_REQUIRE(x && gy && gw, "conv1d_wgrad: null x/gy/gw pointer");
     const WgradPlan p = plan_wgrad(B, Cin, Cout, T, K);
@@ -899,17 +992,28 @@ extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, f
     a.nci = p.nci; a.nsplit = p.nsplit; a.iters = p.iters;
     a.vec = (T % 4 == 0) ? 1 : 0;
     hipStream_t st = as_stream(stream);
-    constexpr size_t lds = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
+    constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);  // one buffer: gy tile + x tile
+    const bool full = Cin % 64 == 0 && Cout % 64 == 0 && T % 32 == 0;
     dim3 grid(p.nsplit, p.regions);
-    if (K == 3)
-        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), lds, st, a);
+    if (K == 3 && full) {
+        static bool ready = false;  // two buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once)
+        if (!ready) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+            EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e));
+            ready = true;
+        }
+        hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
+    } else if (K == 3) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<3, false>), grid, dim3(256), lds1, st, a);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, dim3(256), lds1, st, a);
+    }
     if (check_launch("conv1d_wgrad")) return 1;
     const long long E = (long long)p.slab_elems;
     const int nb_w = (int)((E + 63) / 64), nb_b = gb ? (Cout + 63) / 64 : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, st, a.ws, p.nsplit, E,
-                       in_scale, gw, nb_w, a.ws_b, (long long)Cout, gb);
+                       in_scale, gw, nb_w, a.ws_b, (long long)Cout, gb, beta_w, beta_b);
     if (check_launch("conv1d_wgrad reduce")) return 1;
     return 0;
 }

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv_args.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace eeggan {
@@ -32,8 +33,12 @@ static_assert(64 * EL <= XREG, "output tile must fit the wave's region");
 __device__ __forceinline__ int xrow(int row) { return row * XL + (row >= 32 ? 32 : 0); }
 
 // K taps; MASKED: the input is multiplied by a saved LeakyReLU/GDrop mask while it is staged;
-// FULL: Cin == Cout == 64 and T % 32 == 0, so no load or store needs a predicate.
-template <int K, bool MASKED, bool FULL>
+// FULL: Cin == Cout == 64 and T % 32 == 0, so no load or store needs a predicate;
+// RM: 32-channel output tiles per unit.  RM = 2: a unit is a whole subtile (all 64 output channels).
+// RM = 1: a unit is one half of the output channels of a subtile (units 2s and 2s+1 share subtile s
+// and are taken by neighbouring waves): twice the input reads, but twice as many, half as long units,
+// which balances the four SIMDs of a CU when a layer has only a few subtiles per CU.
+template <int K, bool MASKED, bool FULL, int RM>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int KK = 64 * K;   // reduction length with the input channels padded to 64
@@ -69,11 +74,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     struct Unit {
         const float* xb;
         const float* mb;
-        int b, t0;
+        int b, t0, half;
         bool t_ok, h_ok;
     };
     auto locate = [&](int unit) {
         Unit r;
+        r.half = RM == 1 ? (unit & 1) : 0;
+        if (RM == 1) unit >>= 1;
         r.b = unit / a.ST;
         r.t0 = (unit - r.b * a.ST) * 32;
         r.xb = a.x + ((long long)r.b * a.Cin) * a.T + r.t0;
@@ -165,7 +172,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     // (a wave without a unit loads unit 0 and drops it: a load inside a branch would make every later
     // wait count conservative, i.e. the weight staging below would wait for the input as well)
     EEGGAN_STAMP(15, 0);
-    const bool active = wave < a.wpb && u < a.NS;
+    const int nunits = a.NS * (3 - RM);
+    const bool active = wave < a.wpb && u < nunits;
     Unit cur = locate(active ? u : 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) issue_chunk(cur, c);
@@ -216,10 +224,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         constexpr bool MORE = decltype(more_tag)::value;
         EEGGAN_STAMP(step, 0);
         const bool st_ok = cur.t_ok;
-        float bb[8], dd[8];  // (loaded per unit: hoisted out of the loop, their selects would wait for the input)
+        constexpr int NE = 4 * RM;       // epilogue items of this lane: output rows co_base + r0 + 8 i
+        const int co_base = cur.half * 32;
+        float bb[NE], dd[NE];  // (loaded per unit: hoisted out of the loop, their selects would wait for the input)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (FULL || r0 + 8 * i < a.Cout) ? r0 + 8 * i : 0;
+        for (int i = 0; i < NE; ++i) {
+            const int row = (FULL || co_base + r0 + 8 * i < a.Cout) ? co_base + r0 + 8 * i : 0;
             bb[i] = bias_p[row];
             dd[i] = drop_p[has_drop ? cur.b * a.Cout + row : 0];
         }
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        const float* Au = Ap + co_base * WLD;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             commit_chunk(cur, c);
@@ -235,15 +246,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s4 = c * (2 * K); s4 < (c + 1) * (2 * K); ++s4) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ap + 4 * s4);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ap + 32 * WLD + 4 * s4);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(Au + 4 * s4);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(Au + (RM == 2 ? 32 * WLD : 0) + 4 * s4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int s = 4 * s4 + e;
                     const int cl = s / K, j = s - cl * K;
                     const float bv = Bp[cl * XL + j];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a0[e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a1[e], acc1, 0, 0, 0);
+                    if (RM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a1[e], acc1, 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -263,27 +274,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 v1[e] = acc1[4 * qq + e];
             }
             *reinterpret_cast<f32x4*>(E + l31 * EL + 8 * qq + 4 * h) = v0;
-            *reinterpret_cast<f32x4*>(E + (32 + l31) * EL + 8 * qq + 4 * h) = v1;
+            if (RM == 2) *reinterpret_cast<f32x4*>(E + (32 + l31) * EL + 8 * qq + 4 * h) = v1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        float* yb = a.y + ((long long)cur.b * a.Cout) * a.T + cur.t0;
-        const float* ab = a.act_aux ? a.act_aux + ((long long)cur.b * a.Cout) * a.T + cur.t0 : a.x;
+        float* yb = a.y + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0;
+        const float* ab = a.act_aux ? a.act_aux + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0 : a.x;
         auto run = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
-            f32x4 m[ACT == EEGGAN_ACT_MASK ? 8 : 1];
+            f32x4 m[ACT == EEGGAN_ACT_MASK ? NE : 1];
             if (ACT == EEGGAN_ACT_MASK) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool ok = st_ok && (FULL || r0 + 8 * i < a.Cout);
+                for (int i = 0; i < NE; ++i) {
+                    const bool ok = st_ok && (FULL || co_base + r0 + 8 * i < a.Cout);
                     m[ACT == EEGGAN_ACT_MASK ? i : 0] =
                         *reinterpret_cast<const f32x4*>(ok ? ab + ylo + 8 * i * a.T : a.act_aux);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = r0 + 8 * i;
+            for (int i = 0; i < NE; ++i) {
+                const int row = r0 + 8 * i;  // row of the unit's tile; output channel co_base + row
                 f32x4 v = *reinterpret_cast<const f32x4*>(E + row * EL + 4 * q);
                 const float bias_v = has_bias ? bb[i] : 0.f;
                 const float drop_v = has_drop ? dd[i] : 1.f;
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                     if (ACT == EEGGAN_ACT_MASK) t = m[ACT == EEGGAN_ACT_MASK ? i : 0][e] > 0.f ? t : t * a.act_param;
                     v[e] = t * drop_v;
                 }
-                if (FULL || (st_ok && row < a.Cout)) *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
+                if (FULL || (st_ok && co_base + row < a.Cout)) *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
             }
         };
         switch (a.act) {
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int nu = u + ustride; nu < a.NS; nu += ustride, ++step) {
+    for (int nu = u + ustride; nu < nunits; nu += ustride, ++step) {
         const Unit nxt = locate(nu);
         unit_body(std::true_type{}, nxt);
         cur = nxt;
@@ -317,10 +328,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     unit_body(std::false_type{}, cur);
 }
 
-template <int K, bool MASKED, bool FULL>
+template <int K, bool MASKED, bool FULL, int RM>
 int launch(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(64 * (64 * K + 4) + WS_WAVES * XREG) * sizeof(float);
-    auto kernel = &conv_ws_kernel<K, MASKED, FULL>;
+    auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM>;
     static bool ready = false;  // opt in to > 64 KiB of dynamic LDS (once)
     if (!ready) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -332,12 +343,22 @@ int launch(const ConvArgs& a, hipStream_t st) {
         ready = true;
     }
     ConvArgs b = a;
-    b.wpb = (a.NS + num_cus() - 1) / num_cus();
+    const long long units = (long long)a.NS * (3 - RM);
+    b.wpb = (int)((units + num_cus() - 1) / num_cus());
     if (b.wpb > WS_WAVES) b.wpb = WS_WAVES;
-    long long grid = (a.NS + b.wpb - 1) / b.wpb;
+    if (RM == 1 && (b.wpb & 1)) ++b.wpb;  // both halves of a subtile in the same workgroup
+    long long grid = (units + b.wpb - 1) / b.wpb;
     if (grid > num_cus()) grid = num_cus();
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, st, b);
     return check_launch("conv1d");
+}
+
+template <int K, bool MASKED, bool FULL>
+int launch_rm(const ConvArgs& a, hipStream_t st) {
+    // whole-subtile units once every SIMD has at least two of them to interleave, half units below
+    static const int force = getenv("EEGGAN_WS_RM") ? atoi(getenv("EEGGAN_WS_RM")) : 0;  // timing experiments only
+    const bool halves = force ? force == 1 : a.NS < 8 * num_cus();
+    return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
 
 }  // namespace
@@ -346,8 +367,8 @@ int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st) {
     if (K != 3 || a.Cin > 64 || a.Cout > 64 || a.Cout <= 32 || a.T % 4 != 0 || a.NS < 256) return -1;
     if ((long long)a.Cin * a.T * 2 >= (1ll << 31) || (long long)a.Cout * a.T * 2 >= (1ll << 31)) return -1;
     const bool full = a.Cin == 64 && a.Cout == 64 && a.T % 32 == 0;
-    if (a.mask_y) return full ? launch<3, true, true>(a, st) : launch<3, true, false>(a, st);
-    return full ? launch<3, false, true>(a, st) : launch<3, false, false>(a, st);
+    if (a.mask_y) return full ? launch_rm<3, true, true>(a, st) : launch_rm<3, true, false>(a, st);
+    return full ? launch_rm<3, false, true>(a, st) : launch_rm<3, false, false>(a, st);
 }
 
 }  // namespace eeggan

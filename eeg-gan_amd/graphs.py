@@ -107,7 +107,8 @@ class GraphedTrainer(Trainer):
 
             def fwd_bwd():
                 loss = loss_fn(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
-                loss.backward()
+                with ops.direct_weight_grads(self.direct_grads):
+                    loss.backward()
                 if bucketed:
                     box["bucket"] = sync.pack(module)
                 else:

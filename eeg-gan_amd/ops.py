@@ -127,7 +127,10 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
     return y
 
 
-def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mask_drop=None, mask_slope=0.0):
+def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mask_drop=None, mask_slope=0.0,
+                     out_w=None, out_b=None, beta_w=0.0, beta_b=0.0):
+    """Weight/bias gradient.  ``out_w``/``out_b``: write into these buffers instead of new tensors,
+    as ``out = beta * out + gradient`` (beta 0: plain overwrite)."""
     x = _chk(x, "wgrad x")
     gy = _chk(gy, "wgrad gy")
     B, Cin, T = x.shape
@@ -139,11 +142,94 @@ def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mas
             raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
     nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    gw = torch.empty((Cout, Cin, K), device=x.device, dtype=torch.float32)
-    gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+    gw = out_w if out_w is not None else torch.empty((Cout, Cin, K), device=x.device, dtype=torch.float32)
+    gb = out_b if out_b is not None else (
+        torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None)
+    if tuple(gw.shape) != (Cout, Cin, K) or not gw.is_contiguous() or (gb is not None and gb.numel() != Cout):
+        raise RuntimeError("conv1d_wgrad: output buffers do not match the weight/bias shapes")
     call("eeggan_conv1d_wgrad", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), _p(gb), B, Cin, Cout, T, K,
-         float(in_scale), _p(mask_y), _p(mask_drop), float(mask_slope), ws.data_ptr(), nbytes, _stream())
+         float(in_scale), _p(mask_y), _p(mask_drop), float(mask_slope), float(beta_w), float(beta_b),
+         ws.data_ptr(), nbytes, _stream())
     return gw, gb
+
+
+# --------------------------------------------------------------------------------------- direct weight gradients
+# Inside ``direct_weight_grads()`` a plain ``loss.backward()`` does not hand conv weight gradients to
+# autograd: each one is computed on a side stream straight into a persistent per-parameter buffer
+# (accumulating when the parameter already received a contribution), and the buffers become
+# ``p.grad`` in an end-of-backward callback that also joins the side stream.  That takes the
+# weight-gradient kernels -- a quarter of the launches of a step, none of them on the dependency
+# chain of the backward pass -- off the main stream, where every launch costs ~4 us of dispatch
+# latency, and removes autograd's accumulation kernels.  Semantics as torch's: ``p.grad`` is summed
+# into until someone sets it to None (``zero_grad``).  Not used while a graph for double backward
+# is being built (grad mode on) nor by ``torch.autograd.grad``-style calls outside the context.
+class _DirectGrads:
+    def __init__(self):
+        self.enabled = False
+        self.side = {}
+        self.main = None
+        self.keep = []      # tensors the side stream still reads
+        self.touched = {}   # id(param) -> param, this backward pass
+        self.queued = False
+
+    def usable(self, w):
+        return self.enabled and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.is_cuda
+
+    def _slot(self, p):
+        buf = getattr(p, "_eeggan_grad", None)
+        if buf is None or buf.shape != p.shape or buf.device != p.device:
+            buf = torch.empty_like(p, memory_format=torch.contiguous_format)
+            p._eeggan_grad = buf
+        if id(p) in self.touched:
+            beta = 1.0
+        elif p.grad is None:
+            beta = 0.0
+        elif p.grad is buf:
+            beta = 1.0
+        else:  # a gradient that came from elsewhere: continue from a copy of it
+            buf.copy_(p.grad)
+            beta = 1.0
+        self.touched[id(p)] = p
+        return buf, beta
+
+    def wgrad(self, w, bias, x, gy, in_scale, mask_y, mask_drop, slope):
+        wbuf, beta_w = self._slot(w)
+        bbuf, beta_b = self._slot(bias) if bias is not None else (None, 0.0)
+        main = torch.cuda.current_stream(w.device)
+        side = self.side.get(w.device)
+        if side is None:
+            side = self.side[w.device] = torch.cuda.Stream(w.device)
+        if self.main is None:
+            self.main = main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            conv1d_wgrad_raw(x, gy, w.shape[2], in_scale=in_scale, need_bias=bias is not None, mask_y=mask_y,
+                             mask_drop=mask_drop, mask_slope=slope, out_w=wbuf, out_b=bbuf, beta_w=beta_w,
+                             beta_b=beta_b)
+        self.keep.extend(t for t in (x, gy, mask_y, mask_drop) if t is not None)
+        if not self.queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+            self.queued = True
+
+    def finish(self):
+        main = self.main if self.main is not None else torch.cuda.current_stream()
+        for side in self.side.values():
+            main.wait_stream(side)
+        for p in self.touched.values():
+            p.grad = p._eeggan_grad
+        self.touched, self.keep, self.queued, self.main = {}, [], False, None
+
+
+_direct = _DirectGrads()
+
+
+@contextlib.contextmanager
+def direct_weight_grads(enabled=True):
+    prev, _direct.enabled = _direct.enabled, bool(enabled)
+    try:
+        yield
+    finally:
+        _direct.enabled = prev
 
 
 def lrelu_drop_bwd_raw(g, y, drop, slope):
@@ -247,8 +333,11 @@ class _ConvT(Function):
             else:
                 g_gy = conv1d_raw(q, w, None, None, in_scale=ctx.in_scale)
         if ctx.needs_input_grad[1] and not _input_grad_only:
-            g_w, _ = conv1d_wgrad_raw(q, gy, w.shape[2], in_scale=ctx.in_scale, need_bias=False, mask_y=mask_y,
-                                      mask_drop=mask_drop, mask_slope=ctx.slope)
+            if _direct.usable(w):
+                _direct.wgrad(w, None, q, gy, ctx.in_scale, mask_y, mask_drop, ctx.slope)
+            else:
+                g_w, _ = conv1d_wgrad_raw(q, gy, w.shape[2], in_scale=ctx.in_scale, need_bias=False, mask_y=mask_y,
+                                          mask_drop=mask_drop, mask_slope=ctx.slope)
         return g_gy, g_w, None, None, None, None, None
 
 
@@ -263,19 +352,22 @@ class _Conv(Function):
         if act == ACT_NONE and drop is not None:
             raise ValueError("a drop multiplier needs the leaky-relu epilogue")
         y = conv1d_raw(x, w, bias, drop, in_scale=in_scale, act=act, act_param=slope)
-        ctx.save_for_backward(x, w, drop, y if act == ACT_LRELU else None)
+        ctx.save_for_backward(x, w, drop, y if act == ACT_LRELU else None, bias)
         ctx.in_scale, ctx.slope, ctx.has_bias = in_scale, slope, bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, drop, y = ctx.saved_tensors
+        x, w, drop, y, bias = ctx.saved_tensors
         gy = _chk(gy, "conv grad")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _ConvT.apply(gy, w, y, drop, ctx.in_scale, ctx.slope, ctx.flip)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
-            gw, gb = _WGrad.apply(x, gy, w.shape[2], ctx.in_scale, ctx.has_bias, y, drop, ctx.slope)
+            if _direct.usable(w) and (bias is None or _direct.usable(bias)):
+                _direct.wgrad(w, bias, x, gy, ctx.in_scale, y, drop, ctx.slope)
+            else:
+                gw, gb = _WGrad.apply(x, gy, w.shape[2], ctx.in_scale, ctx.has_bias, y, drop, ctx.slope)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -417,14 +509,14 @@ class _GLayer(Function):
             y = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_TANH, act_param=tanh_scale)
         else:
             raise ValueError(mode)
-        ctx.save_for_backward(x, w, drop, y, d)
+        ctx.save_for_backward(x, w, drop, y, d, bias)
         ctx.cfg = (in_scale, slope, mode, kind, tanh_scale, bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, w, drop, y, d = ctx.saved_tensors
+        x, w, drop, y, d, bias = ctx.saved_tensors
         in_scale, slope, mode, kind, tanh_scale, has_bias = ctx.cfg
         gy = _chk(gy, "G layer grad")
         if mode == "tanh":
@@ -451,7 +543,10 @@ class _GLayer(Function):
             if ctx.needs_input_grad[0]:
                 gx = conv1d_raw(gc, w, None, None, in_scale=in_scale, transposed=True, flip=ctx.flip)
             if need_w:
-                gw, gb = conv1d_wgrad_raw(x, gc, w.shape[2], in_scale=in_scale, need_bias=has_bias)
+                if _direct.usable(w) and (bias is None or _direct.usable(bias)):
+                    _direct.wgrad(w, bias, x, gc, in_scale, None, None, 0.0)
+                else:
+                    gw, gb = conv1d_wgrad_raw(x, gc, w.shape[2], in_scale=in_scale, need_bias=has_bias)
         return gx, gw, gb, None, None, None, None, None, None, None
 
 

@@ -5,10 +5,14 @@ from __future__ import annotations
 
 import heapq
 
+from . import ops
 from .utils import cudize
 
 
 class Trainer(object):
+    # conv weight gradients go straight into persistent buffers on a side stream (ops.direct_weight_grads)
+    direct_grads = True
+
     def __init__(self, discriminator, generator, d_loss, g_loss, dataset, random_latents_generator, resume_nimg,
                  optimizer_g, optimizer_d, d_training_repeats: int = 5, tick_kimg_default: float = 5.0):
         assert d_training_repeats >= 1
@@ -78,7 +82,8 @@ class Trainer(object):
         self.call_plugins("end", 1)
 
     def _step(self, loss, optimizer, module):
-        loss.backward()
+        with ops.direct_weight_grads(self.direct_grads):
+            loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(module, optimizer)
         else:

@@ -61,12 +61,16 @@ int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int
  *   gw[co,ci,j] = in_scale * sum_{b,t} gy[b,co,t] * x[b,ci,t+j-pad],  gb[co] = sum_{b,t} gy[b,co,t]
  * gb may be NULL.  If mask_y != NULL, gy is first multiplied by
  * mask_drop[b,co] * (mask_y[b,co,t] > 0 ? 1 : mask_slope) as above.
+ * The results are ACCUMULATED when the factors are non-zero: gw = beta_w * gw + (the sum above),
+ * gb = beta_b * gb + (...); with a factor of 0 the old contents are never read (torch's autograd
+ * does this accumulation with an extra add kernel per contribution, reference trainer.py:88-94).
  * `workspace` must hold eeggan_conv1d_wgrad_workspace(...) bytes; the sum over the
  * partial slabs is done in a fixed order, so results are run-to-run deterministic. */
 size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T, int K);
 int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb,
                         int B, int Cin, int Cout, int T, int K, float in_scale,
                         const float* mask_y, const float* mask_drop, float mask_slope,
+                        float beta_w, float beta_b,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal (network.py:158-159,302-303) --

@@ -359,17 +359,32 @@ def _same_trajectory(base, other, what):
     assert moved > 0
 
 
+def _autograd_trainer():
+    """Trainer whose weight gradients take torch's own route (returned to autograd, accumulated by it)."""
+    from eeggan_amd.trainer import Trainer
+
+    class AutogradTrainer(Trainer):
+        direct_grads = False
+
+    return AutogradTrainer
+
+
 def test_graph_replay_equals_eager(dev):
-    """Two training steps through captured HIP graphs follow the eager trajectory."""
+    """Two training steps follow the same trajectory (a) with weight gradients accumulated by autograd
+    on one stream, (b) with the trainer's default side-stream accumulation into persistent buffers,
+    (c) replayed from captured HIP graphs."""
     from eeggan_amd import layers
     from eeggan_amd.graphs import GraphedTrainer
     from eeggan_amd.trainer import Trainer
     layers.set_drop_mode("device")
     try:
-        base = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
+        plain = _autograd_trainer()
+        base = _two_steps(dev, plain, lr=0.0), _two_steps(dev, plain)
+        direct = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
         graphed = _two_steps(dev, GraphedTrainer, lr=0.0), _two_steps(dev, GraphedTrainer)
     finally:
         layers.set_drop_mode("numpy")
+    _same_trajectory(base, direct, "side-stream weight gradients")
     _same_trajectory(base, graphed, "graph replay")
 
 
