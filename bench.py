@@ -107,7 +107,7 @@ def conv_roofline(dev, batch, T):
     sec = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * batch * C * C * K * T
     achieved = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "conv_fwd_kernel<K=3,CT=64,NT=4,CK=32> (64->64 ch, k=3, T=1920, fused bias+lrelu+drop)",
+    return {"bound": "mfma", "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop)" % batch,
             "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
             "avg_launch_us": round(sec * 1e6, 2), "flop_per_launch": flops}
@@ -140,13 +140,23 @@ def cpu_baseline(depth, alpha, batch, seed):
 
 def main():
     args = parse()
+    if os.environ.get("EEGGAN_HANG_DUMP"):  # debugging aid: stack dump of every thread after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["EEGGAN_HANG_DUMP"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        # EEGGAN_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+        backend = os.environ.get("EEGGAN_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
     if not torch.cuda.is_available():
@@ -178,7 +188,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -155,12 +156,11 @@ def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mas
 
 # --------------------------------------------------------------------------------------- direct weight gradients
 # Inside ``direct_weight_grads()`` a plain ``loss.backward()`` does not hand conv weight gradients to
-# autograd: each one is computed on a side stream straight into a persistent per-parameter buffer
-# (accumulating when the parameter already received a contribution), and the buffers become
-# ``p.grad`` in an end-of-backward callback that also joins the side stream.  That takes the
-# weight-gradient kernels -- a quarter of the launches of a step, none of them on the dependency
-# chain of the backward pass -- off the main stream, where every launch costs ~4 us of dispatch
-# latency, and removes autograd's accumulation kernels.  Semantics as torch's: ``p.grad`` is summed
+# autograd: each one is computed straight into a persistent per-parameter buffer (the kernel
+# accumulates when the parameter already received a contribution), and the buffers become ``p.grad``
+# in an end-of-backward callback.  That removes autograd's accumulation kernels (one tiny launch per
+# contribution and tensor) and the allocation of a gradient tensor per call; optionally
+# (EEGGAN_WGRAD_STREAM=side) the kernels run on a second stream joined by the same callback.  Semantics as torch's: ``p.grad`` is summed
 # into until someone sets it to None (``zero_grad``).  Not used while a graph for double backward
 # is being built (grad mode on) nor by ``torch.autograd.grad``-style calls outside the context.
 class _DirectGrads:
@@ -171,6 +171,12 @@ class _DirectGrads:
         self.keep = []      # tensors the side stream still reads
         self.touched = {}   # id(param) -> param, this backward pass
         self.queued = False
+        # Measured at the final stage: running the weight-gradient kernels on a second stream gains
+        # < 1 % (every conv kernel fills the chip by itself), so the default keeps them on the main
+        # stream; the gain of this path is the accumulation done by the kernel itself.
+        self.batch = int(os.environ.get("EEGGAN_WGRAD_BATCH", "1"))   # launches per flush
+        self.use_side = os.environ.get("EEGGAN_WGRAD_STREAM", "main") == "side"
+        self.todo = []
 
     def usable(self, w):
         return self.enabled and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.is_cuda
@@ -196,22 +202,37 @@ class _DirectGrads:
         wbuf, beta_w = self._slot(w)
         bbuf, beta_b = self._slot(bias) if bias is not None else (None, 0.0)
         main = torch.cuda.current_stream(w.device)
-        side = self.side.get(w.device)
-        if side is None:
-            side = self.side[w.device] = torch.cuda.Stream(w.device)
         if self.main is None:
             self.main = main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            conv1d_wgrad_raw(x, gy, w.shape[2], in_scale=in_scale, need_bias=bias is not None, mask_y=mask_y,
-                             mask_drop=mask_drop, mask_slope=slope, out_w=wbuf, out_b=bbuf, beta_w=beta_w,
-                             beta_b=beta_b)
+        self.todo.append((x, gy, w.shape[2], dict(in_scale=in_scale, need_bias=bias is not None, mask_y=mask_y,
+                                                   mask_drop=mask_drop, mask_slope=slope, out_w=wbuf, out_b=bbuf,
+                                                   beta_w=beta_w, beta_b=beta_b)))
         self.keep.extend(t for t in (x, gy, mask_y, mask_drop) if t is not None)
+        if len(self.todo) >= self.batch:
+            self.flush()
         if not self.queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self.queued = True
 
+    def flush(self):
+        if not self.todo:
+            return
+        main = self.main
+        if self.use_side:
+            side = self.side.get(main.device)
+            if side is None:
+                side = self.side[main.device] = torch.cuda.Stream(main.device)
+            side.wait_stream(main)
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = torch.cuda.stream(main)
+        with ctx:
+            for x, gy, K, kw in self.todo:
+                conv1d_wgrad_raw(x, gy, K, **kw)
+        self.todo = []
+
     def finish(self):
+        self.flush()
         main = self.main if self.main is not None else torch.cuda.current_stream()
         for side in self.side.values():
             main.wait_stream(side)

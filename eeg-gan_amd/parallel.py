@@ -85,7 +85,14 @@ class DataParallelStep:
         return bucket
 
     def reduce(self, bucket: GradBucket) -> None:
-        if dist.is_available() and dist.is_initialized():
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if bucket.flat.is_cuda and dist.get_backend(self.pg) != "nccl":
+            # a host-side backend (rehearsals of the multi-rank path without one GPU per rank)
+            host = bucket.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+            bucket.flat.copy_(host)
+        else:
             dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
 
     def apply(self, optimizer, bucket: GradBucket) -> None:
