@@ -30,6 +30,7 @@ SIGNATURES = {
     "eeggan_abi_version": (_i, []),
     "eeggan_conv1d": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _fl, _f, _f, _f, _fl, _st]),
     "eeggan_conv1d_flip_weights": (_i, [_f, _f, _i, _i, _i, _st]),
+    "eeggan_conv1d_flip_weights_multi": (_i, [C.c_void_p, _i, _st]),
     "eeggan_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "eeggan_conv1d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _f, _fl, _fl, _fl, _f, _sz, _st]),
     "eeggan_head_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),

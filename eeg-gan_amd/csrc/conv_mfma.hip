@@ -657,6 +657,35 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restri
     wt[i] = w[((long long)co * Cin + ci) * K + (K - 1 - j)];
 }
 
+// Same for up to 64 weight tensors in one launch (descriptor table by value in the kernel arguments):
+// a network's flipped views all go stale together, at its optimizer step.
+constexpr int FLIP_MAXT = 64;
+struct FlipPack {
+    eeggan_flip_desc t[FLIP_MAXT];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void flip_weights_multi_kernel(FlipPack pk) {
+    long long blk = blockIdx.x;
+    for (int k = 0; k < pk.n; ++k) {
+        const eeggan_flip_desc d = pk.t[k];
+        const long long n = (long long)d.Cout * d.Cin * d.K;
+        const long long nb = (n + 255) / 256;
+        if (blk < nb) {
+            const long long i = blk * 256 + threadIdx.x;
+            if (i < n) {
+                const int j = (int)(i % d.K);
+                const long long r = i / d.K;
+                const int co = (int)(r % d.Cout);
+                const int ci = (int)(r / d.Cout);
+                d.wt[i] = d.w[((long long)co * d.Cin + ci) * d.K + (d.K - 1 - j)];
+            }
+            return;
+        }
+        blk -= nb;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight gradient.  A workgroup owns a 64(co) x 64(ci) x K region of gw and a contiguous
 // range of subtile pairs; wave w accumulates the 32x32xK tile (co half = w>>1, ci half = w&1).
@@ -966,6 +995,25 @@ extern "C" int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, i
     hipLaunchKernelGGL(flip_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), w, wt,
                        Cout, Cin, K);
     return check_launch("conv1d_flip_weights");
+}
+
+extern "C" int eeggan_conv1d_flip_weights_multi(const eeggan_flip_desc* table, int ntensors, void* stream) {
+    EEGGAN_REQUIRE(table && ntensors > 0, "conv1d_flip_weights_multi: bad table");
+    for (int first = 0; first < ntensors; first += FLIP_MAXT) {
+        FlipPack pk;
+        pk.n = ntensors - first < FLIP_MAXT ? ntensors - first : FLIP_MAXT;
+        long long blocks = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            pk.t[i] = table[first + i];
+            EEGGAN_REQUIRE(pk.t[i].w && pk.t[i].wt && pk.t[i].Cout > 0 && pk.t[i].Cin > 0 && pk.t[i].K > 0,
+                           "conv1d_flip_weights_multi: bad descriptor %d", first + i);
+            blocks += ((long long)pk.t[i].Cout * pk.t[i].Cin * pk.t[i].K + 255) / 256;
+        }
+        EEGGAN_REQUIRE(blocks < (1ll << 31), "conv1d_flip_weights_multi: too many elements");
+        hipLaunchKernelGGL(flip_weights_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pk);
+        if (check_launch("conv1d_flip_weights_multi")) return 1;
+    }
+    return 0;
 }
 
 extern "C" size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T, int K) {

@@ -16,6 +16,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -77,21 +78,48 @@ def _flip_into(w, wt):
     return wt
 
 
+class _FlipDesc(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("wt", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("K", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 class FlipCache:
+    """Flipped view of one weight.  All caches are registered: when one is found stale, every stale
+    cache on the same device is rebuilt by the same launch (the views of a network go stale together,
+    at its optimizer step, and each is needed a few kernels later)."""
+
+    _all = weakref.WeakSet()
+
     def __init__(self, param):
         self.param = param
         self.tag = None
         self.wt = None
+        self.used = False  # only views that some input-gradient launch has asked for are kept up to date
+        FlipCache._all.add(self)
+
+    def _current_tag(self):
+        p = self.param
+        return (p.data_ptr(), p._version, _weights_epoch)
+
+    def _stale(self):
+        return self.tag != self._current_tag()
 
     def get(self):
-        p = self.param
-        tag = (p.data_ptr(), p._version, _weights_epoch)
-        if tag != self.tag:
-            cout, cin, k = p.shape
-            if self.wt is None or self.wt.device != p.device:
-                self.wt = torch.empty((cin, cout, k), device=p.device, dtype=torch.float32)
-            _flip_into(p.detach(), self.wt)
-            self.tag = tag
+        self.used = True
+        if self._stale():
+            dev = self.param.device
+            todo = [c for c in FlipCache._all if c.used and c.param.device == dev and c.param.is_cuda and c._stale()]
+            table = (_FlipDesc * len(todo))()
+            for i, c in enumerate(todo):
+                p = c.param
+                cout, cin, k = p.shape
+                if c.wt is None or c.wt.device != dev or c.wt.numel() != p.numel():
+                    c.wt = torch.empty((cin, cout, k), device=dev, dtype=torch.float32)
+                table[i].w, table[i].wt = p.data_ptr(), c.wt.data_ptr()
+                table[i].Cout, table[i].Cin, table[i].K = cout, cin, k
+            call("eeggan_conv1d_flip_weights_multi", table, len(todo), _stream())
+            for c in todo:
+                c.tag = c._current_tag()
         return self.wt
 
 

@@ -56,6 +56,12 @@ int eeggan_conv1d(const float* x, const float* w, const float* bias, const float
                   const float* mask_y, const float* mask_drop, float mask_slope,
                   void* stream);
 int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, void* stream);
+/* The same for a table of weight tensors (host array, copied into the kernel arguments) in one
+ * launch: all views of a network go stale together when its optimizer steps (trainer.py:90,94). */
+typedef struct {
+    const float* w; float* wt; int Cout, Cin, K, reserved;
+} eeggan_flip_desc;
+int eeggan_conv1d_flip_weights_multi(const eeggan_flip_desc* table, int ntensors, void* stream);
 
 /* Weight- and bias-gradient of the same convolution (autograd of nn.Conv1d, layers.py:154-155):
  *   gw[co,ci,j] = in_scale * sum_{b,t} gy[b,co,t] * x[b,ci,t+j-pad],  gb[co] = sum_{b,t} gy[b,co,t]
