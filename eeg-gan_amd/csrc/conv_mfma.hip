@@ -1021,25 +1021,27 @@ extern "C" size_t eeggan_conv1d_wgrad_workspace(int B, int Cin, int Cout, int T,
     return plan_wgrad(B, Cin, Cout, T, K).bytes;
 }
 
-extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
-                                   int T, int K, float in_scale, const float* mask_y, const float* mask_drop,
-                                   float mask_slope, float beta_w, float beta_b, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+namespace eeggan {
+namespace {
+
+// Launches the partial-slab kernel; the slabs (and bias slabs when want_bias) land in `workspace`.
+int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool want_bias, int B, int Cin, int Cout,
+                         int T, int K, const float* mask_y, const float* mask_drop, float mask_slope,
+                         void* workspace, size_t workspace_bytes, hipStream_t st, WgradPlan* plan, float** ws_b) {
     if (check_common(B, Cin, Cout, T, K)) return 1;
-    EEGGAN_REQUIRE(x && gy && gw, "conv1d_wgrad: null x/gy/gw pointer");
+    EEGGAN_REQUIRE(x && gy, "%s: null x/gy pointer", what);
     const WgradPlan p = plan_wgrad(B, Cin, Cout, T, K);
-    EEGGAN_REQUIRE(workspace && workspace_bytes >= p.bytes, "conv1d_wgrad: workspace too small (%zu < %zu bytes)",
+    EEGGAN_REQUIRE(workspace && workspace_bytes >= p.bytes, "%s: workspace too small (%zu < %zu bytes)", what,
                    workspace_bytes, p.bytes);
     WgradArgs a;
     a.x = x; a.gy = gy; a.mask_y = mask_y; a.mask_drop = mask_y ? mask_drop : nullptr; a.mask_slope = mask_slope;
     a.ws = static_cast<float*>(workspace);
-    a.ws_b = gb ? a.ws + (size_t)p.nsplit * p.slab_elems : nullptr;
+    a.ws_b = want_bias ? a.ws + (size_t)p.nsplit * p.slab_elems : nullptr;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
     a.ST = (T + 31) / 32;
     a.NS = B * a.ST;
     a.nci = p.nci; a.nsplit = p.nsplit; a.iters = p.iters;
     a.vec = (T % 4 == 0) ? 1 : 0;
-    hipStream_t st = as_stream(stream);
     constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);  // one buffer: gy tile + x tile
     const bool full = Cin % 64 == 0 && Cout % 64 == 0 && T % 32 == 0;
     dim3 grid(p.nsplit, p.regions);
@@ -1048,7 +1050,7 @@ extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, f
         if (!ready) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
-            EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e));
+            EEGGAN_REQUIRE(e == hipSuccess, "%s: cannot reserve LDS: %s", what, hipGetErrorString(e));
             ready = true;
         }
         hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
@@ -1057,11 +1059,123 @@ extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, f
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<1, false>), grid, dim3(256), lds1, st, a);
     }
-    if (check_launch("conv1d_wgrad")) return 1;
+    if (check_launch(what)) return 1;
+    *plan = p;
+    *ws_b = a.ws_b;
+    return 0;
+}
+
+// Many slab reductions in one launch (descriptor table by value); a workgroup finds its job by
+// walking the table.  Jobs of one launch must write distinct outputs.
+constexpr int RED_MAXJ = 48;
+struct ReducePack {
+    eeggan_reduce_job j[RED_MAXJ];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReducePack pk) {
+    __shared__ double part[4][64];
+    long long blk = blockIdx.x;
+    int k = 0;
+    for (; k < pk.n; ++k) {
+        const long long nb = (pk.j[k].elems + 63) / 64;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (k == pk.n) return;
+    const eeggan_reduce_job job = pk.j[k];
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long i = blk * 64 + el, E = job.elems;
+    const int nsplit = job.nsplit;
+    const float* ws = job.slabs;
+    double acc = 0.0;
+    if (i < E) {
+        int s = sg;
+        for (; s + 28 < nsplit; s += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ws[(long long)(s + 4 * u) * E + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; s < nsplit; s += 4) acc += (double)ws[(long long)s * E + i];
+    }
+    part[sg][el] = acc;
+    __syncthreads();
+    if (sg == 0 && i < E) {
+        const float v = (float)(((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) * (double)job.scale);
+        job.out[i] = job.beta != 0.f ? job.beta * job.out[i] + v : v;
+    }
+}
+
+}  // namespace
+}  // namespace eeggan
+
+extern "C" int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int Cin, int Cout,
+                                   int T, int K, float in_scale, const float* mask_y, const float* mask_drop,
+                                   float mask_slope, float beta_w, float beta_b, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    EEGGAN_REQUIRE(gw, "conv1d_wgrad: null gw pointer");
+    hipStream_t st = as_stream(stream);
+    WgradPlan p;
+    float* ws_b;
+    if (launch_wgrad_partial("conv1d_wgrad", x, gy, gb != nullptr, B, Cin, Cout, T, K, mask_y, mask_drop, mask_slope,
+                             workspace, workspace_bytes, st, &p, &ws_b))
+        return 1;
     const long long E = (long long)p.slab_elems;
     const int nb_w = (int)((E + 63) / 64), nb_b = gb ? (Cout + 63) / 64 : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, st, a.ws, p.nsplit, E,
-                       in_scale, gw, nb_w, a.ws_b, (long long)Cout, gb, beta_w, beta_b);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb_w + nb_b)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), p.nsplit, E, in_scale, gw, nb_w, ws_b, (long long)Cout, gb,
+                       beta_w, beta_b);
     if (check_launch("conv1d_wgrad reduce")) return 1;
+    return 0;
+}
+
+extern "C" int eeggan_conv1d_wgrad_partial(const float* x, const float* gy, int want_bias, int B, int Cin, int Cout,
+                                           int T, int K, float in_scale, const float* mask_y, const float* mask_drop,
+                                           float mask_slope, void* workspace, size_t workspace_bytes,
+                                           eeggan_reduce_job* job_w, eeggan_reduce_job* job_b, void* stream) {
+    EEGGAN_REQUIRE(job_w && (!want_bias || job_b), "conv1d_wgrad_partial: null job pointer");
+    WgradPlan p;
+    float* ws_b;
+    if (launch_wgrad_partial("conv1d_wgrad_partial", x, gy, want_bias != 0, B, Cin, Cout, T, K, mask_y, mask_drop,
+                             mask_slope, workspace, workspace_bytes, as_stream(stream), &p, &ws_b))
+        return 1;
+    job_w->slabs = static_cast<const float*>(workspace);
+    job_w->out = nullptr;
+    job_w->elems = (int64_t)p.slab_elems;
+    job_w->nsplit = p.nsplit;
+    job_w->scale = in_scale;
+    job_w->beta = 0.f;
+    if (want_bias) {
+        job_b->slabs = ws_b;
+        job_b->out = nullptr;
+        job_b->elems = Cout;
+        job_b->nsplit = p.nsplit;
+        job_b->scale = 1.f;
+        job_b->beta = 0.f;
+    }
+    return 0;
+}
+
+extern "C" int eeggan_wgrad_reduce_multi(const eeggan_reduce_job* jobs, int njobs, void* stream) {
+    EEGGAN_REQUIRE(jobs && njobs > 0, "wgrad_reduce_multi: bad table");
+    for (int first = 0; first < njobs; first += RED_MAXJ) {
+        ReducePack pk;
+        pk.n = njobs - first < RED_MAXJ ? njobs - first : RED_MAXJ;
+        long long blocks = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            pk.j[i] = jobs[first + i];
+            EEGGAN_REQUIRE(pk.j[i].slabs && pk.j[i].out && pk.j[i].elems > 0 && pk.j[i].nsplit > 0,
+                           "wgrad_reduce_multi: bad job %d", first + i);
+            for (int k = 0; k < i; ++k)
+                EEGGAN_REQUIRE(pk.j[k].out != pk.j[i].out, "wgrad_reduce_multi: jobs %d and %d write the same output",
+                               first + k, first + i);
+            blocks += (pk.j[i].elems + 63) / 64;
+        }
+        EEGGAN_REQUIRE(blocks < (1ll << 31), "wgrad_reduce_multi: too many elements");
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pk);
+        if (check_launch("wgrad_reduce_multi")) return 1;
+    }
     return 0;
 }

@@ -184,27 +184,28 @@ def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mas
 
 # --------------------------------------------------------------------------------------- direct weight gradients
 # Inside ``direct_weight_grads()`` a plain ``loss.backward()`` does not hand conv weight gradients to
-# autograd: each one is computed straight into a persistent per-parameter buffer (the kernel
-# accumulates when the parameter already received a contribution), and the buffers become ``p.grad``
-# in an end-of-backward callback.  That removes autograd's accumulation kernels (one tiny launch per
-# contribution and tensor) and the allocation of a gradient tensor per call; optionally
-# (EEGGAN_WGRAD_STREAM=side) the kernels run on a second stream joined by the same callback.  Semantics as torch's: ``p.grad`` is summed
-# into until someone sets it to None (``zero_grad``).  Not used while a graph for double backward
-# is being built (grad mode on) nor by ``torch.autograd.grad``-style calls outside the context.
+# autograd.  Each one only runs its partial-slab kernel; the slab sums of the whole backward pass are
+# done by a few multi-job launches in an end-of-backward callback, straight into a persistent
+# per-parameter buffer that then becomes ``p.grad`` (accumulating when the parameter already holds a
+# gradient, like torch: ``p.grad`` is summed into until someone sets it to None).  Against the
+# autograd route this removes, per contribution and tensor, one reduce launch, autograd's
+# accumulation kernel and the allocation of a gradient tensor -- ~500 of the ~2300 launches of a
+# training step, each worth ~4 us of dispatch latency.  Not used while a graph for double backward
+# is being built (grad mode on) nor outside the context (``torch.autograd.grad`` keeps its meaning).
+class _ReduceJob(ctypes.Structure):
+    _fields_ = [("slabs", ctypes.c_void_p), ("out", ctypes.c_void_p), ("elems", ctypes.c_int64),
+                ("nsplit", ctypes.c_int), ("scale", ctypes.c_float), ("beta", ctypes.c_float),
+                ("reserved", ctypes.c_int)]
+
+
 class _DirectGrads:
     def __init__(self):
         self.enabled = False
-        self.side = {}
-        self.main = None
-        self.keep = []      # tensors the side stream still reads
-        self.touched = {}   # id(param) -> param, this backward pass
+        self.stream = None
+        self.keep = []      # workspaces the pending reductions still read
+        self.jobs = []      # (round, job): jobs of one round write distinct buffers
+        self.touched = {}   # id(param) -> [param, contributions so far in this backward pass]
         self.queued = False
-        # Measured at the final stage: running the weight-gradient kernels on a second stream gains
-        # < 1 % (every conv kernel fills the chip by itself), so the default keeps them on the main
-        # stream; the gain of this path is the accumulation done by the kernel itself.
-        self.batch = int(os.environ.get("EEGGAN_WGRAD_BATCH", "1"))   # launches per flush
-        self.use_side = os.environ.get("EEGGAN_WGRAD_STREAM", "main") == "side"
-        self.todo = []
 
     def usable(self, w):
         return self.enabled and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.is_cuda
@@ -214,7 +215,8 @@ class _DirectGrads:
         if buf is None or buf.shape != p.shape or buf.device != p.device:
             buf = torch.empty_like(p, memory_format=torch.contiguous_format)
             p._eeggan_grad = buf
-        if id(p) in self.touched:
+        ent = self.touched.get(id(p))
+        if ent is not None:
             beta = 1.0
         elif p.grad is None:
             beta = 0.0
@@ -223,50 +225,45 @@ class _DirectGrads:
         else:  # a gradient that came from elsewhere: continue from a copy of it
             buf.copy_(p.grad)
             beta = 1.0
-        self.touched[id(p)] = p
-        return buf, beta
+        if ent is None:
+            ent = self.touched[id(p)] = [p, 0]
+        rnd = ent[1]
+        ent[1] += 1
+        return buf, beta, rnd
 
     def wgrad(self, w, bias, x, gy, in_scale, mask_y, mask_drop, slope):
-        wbuf, beta_w = self._slot(w)
-        bbuf, beta_b = self._slot(bias) if bias is not None else (None, 0.0)
-        main = torch.cuda.current_stream(w.device)
-        if self.main is None:
-            self.main = main
-        self.todo.append((x, gy, w.shape[2], dict(in_scale=in_scale, need_bias=bias is not None, mask_y=mask_y,
-                                                   mask_drop=mask_drop, mask_slope=slope, out_w=wbuf, out_b=bbuf,
-                                                   beta_w=beta_w, beta_b=beta_b)))
-        self.keep.extend(t for t in (x, gy, mask_y, mask_drop) if t is not None)
-        if len(self.todo) >= self.batch:
-            self.flush()
+        x, gy = _chk(x, "wgrad x"), _chk(gy, "wgrad gy")
+        B, Cin, T = x.shape
+        Cout, K = gy.shape[1], w.shape[2]
+        if gy.shape[0] != B or gy.shape[2] != T or tuple(w.shape) != (Cout, Cin, K):
+            raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)}, gy {tuple(gy.shape)}, w {tuple(w.shape)} disagree")
+        nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        jw, jb = _ReduceJob(), _ReduceJob()
+        call("eeggan_conv1d_wgrad_partial", x.data_ptr(), gy.data_ptr(), int(bias is not None), B, Cin, Cout, T, K,
+             float(in_scale), _p(mask_y), _p(mask_drop), float(slope), ws.data_ptr(), nbytes, ctypes.byref(jw),
+             ctypes.byref(jb), _stream())
+        for p, job in ((w, jw), (bias, jb)):
+            if p is not None:
+                buf, beta, rnd = self._slot(p)
+                job.out, job.beta = buf.data_ptr(), beta
+                self.jobs.append((rnd, job))
+        self.keep.append(ws)
+        self.stream = _stream()
         if not self.queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self.queued = True
 
-    def flush(self):
-        if not self.todo:
-            return
-        main = self.main
-        if self.use_side:
-            side = self.side.get(main.device)
-            if side is None:
-                side = self.side[main.device] = torch.cuda.Stream(main.device)
-            side.wait_stream(main)
-            ctx = torch.cuda.stream(side)
-        else:
-            ctx = torch.cuda.stream(main)
-        with ctx:
-            for x, gy, K, kw in self.todo:
-                conv1d_wgrad_raw(x, gy, K, **kw)
-        self.todo = []
-
     def finish(self):
-        self.flush()
-        main = self.main if self.main is not None else torch.cuda.current_stream()
-        for side in self.side.values():
-            main.wait_stream(side)
-        for p in self.touched.values():
-            p.grad = p._eeggan_grad
-        self.touched, self.keep, self.queued, self.main = {}, [], False, None
+        try:
+            for rnd in sorted({r for r, _ in self.jobs}):
+                jobs = [j for r, j in self.jobs if r == rnd]
+                table = (_ReduceJob * len(jobs))(*jobs)
+                call("eeggan_wgrad_reduce_multi", table, len(jobs), self.stream)
+            for p, _ in self.touched.values():
+                p.grad = p._eeggan_grad
+        finally:
+            self.touched, self.keep, self.jobs, self.queued = {}, [], [], False
 
 
 _direct = _DirectGrads()

@@ -78,6 +78,21 @@ int eeggan_conv1d_wgrad(const float* x, const float* gy, float* gw, float* gb,
                         const float* mask_y, const float* mask_drop, float mask_slope,
                         float beta_w, float beta_b,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves of eeggan_conv1d_wgrad for callers that collect many weight gradients and sum their
+ * partial slabs later in few launches (one backward pass of the critic produces ~50 of them):
+ * eeggan_conv1d_wgrad_partial runs only the slab kernel and fills job_w (and job_b when want_bias)
+ * with slabs/elems/nsplit/scale; the caller sets `out` and `beta` and hands tables of jobs to
+ * eeggan_wgrad_reduce_multi:  out = beta * out + scale * (sum of the nsplit slabs), fixed order.
+ * Jobs of one call must write distinct outputs; the workspace must stay untouched until then. */
+typedef struct {
+    const float* slabs; float* out; int64_t elems; int nsplit; float scale; float beta; int reserved;
+} eeggan_reduce_job;
+int eeggan_conv1d_wgrad_partial(const float* x, const float* gy, int want_bias,
+                                int B, int Cin, int Cout, int T, int K, float in_scale,
+                                const float* mask_y, const float* mask_drop, float mask_slope,
+                                void* workspace, size_t workspace_bytes,
+                                eeggan_reduce_job* job_w, eeggan_reduce_job* job_b, void* stream);
+int eeggan_wgrad_reduce_multi(const eeggan_reduce_job* jobs, int njobs, void* stream);
 
 /* ---- G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal (network.py:158-159,302-303) --
  *   y[b,co,t] = drop[b,co]*act(bias[co] + in_scale * sum_ci w[co,ci,KT-1-t] * z[b,ci]),  t in [0,KT)
