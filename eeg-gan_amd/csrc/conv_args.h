@@ -22,7 +22,6 @@ struct ConvArgs {
     const float* act_aux;
     int vec;  // T % 4 == 0: 16-byte global loads are aligned
     int wpb;    // weight-stationary kernel: waves per workgroup that take work units
-    int debug;  // timing experiments only (EEGGAN_DEBUG): 1 no MFMA, 2 no restaging, 4 no stores
 #ifdef EEGGAN_TRACE
     unsigned long long* trace;  // [4 traced blocks][8 waves][TRACE_STEPS][8] shader-clock stamps
 #endif

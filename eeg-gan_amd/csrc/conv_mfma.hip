@@ -454,14 +454,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                 p_tile += gridDim.x;
                 setup_tile(p_tile);
             }
-            if (!(a.debug & 2)) prefetch();
+            prefetch();
             __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
         }
         EEGGAN_STAMP(step, 1);
         const float* buf = smem + (step & 1) * BUF;
         const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
         const float* Bp = buf + CT * WLD + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
-        if (!(a.debug & 1))
 #pragma unroll
         for (int s4 = 0; s4 < KH / 4; ++s4) {
             f32x4 av[RM];
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
                             }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= dd;
-                            if (!(a.debug & 4)) {
+                            {
                                 if (VEC) {
                                     if (ok) *reinterpret_cast<f32x4*>(a.y + o) = v;
                                 } else {
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and their consumers below it
         EEGGAN_STAMP(step, 3);
-        if (more && !(a.debug & 2)) commit(smem + ((step + 1) & 1) * BUF);
+        if (more) commit(smem + ((step + 1) & 1) * BUF);
         EEGGAN_STAMP(step, 4);
         __syncthreads();
         EEGGAN_STAMP(step, 5);
@@ -624,20 +623,12 @@ template <int K>
 int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     const long long ns = a.NS;
     auto tiles = [&](int ct, int nt) { return ((ns + nt - 1) / nt) * ((a.Cout + ct - 1) / ct); };
-    static const bool no_ws = getenv("EEGGAN_NO_WS") != nullptr;  // timing experiments only
-    if (!no_ws) {
+    {
         const int rc = launch_conv_ws(a, K, st);
         if (rc >= 0) return rc;
     }
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
     if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
-    if (K == 3) {
-        static const int cfg = getenv("EEGGAN_CFG") ? atoi(getenv("EEGGAN_CFG")) : -1;
-        if (cfg == 0) return launch_fwd<3, 64, 4, 32, 1, 4, true>(a, st);
-        if (cfg == 1) return launch_fwd<3, 64, 2, 32, 2, 2, true>(a, st);
-        if (cfg == 2) return launch_fwd<3, 64, 4, 16, 1, 4, true>(a, st);
-        if (cfg == 3) return launch_fwd<3, 64, 2, 16, 2, 2, true>(a, st);
-    }
     const bool full = a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.T % 32 == 0;
     if (tiles(64, 4) >= num_cus())
         return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
@@ -982,8 +973,6 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     a.NS = B * a.ST;
     a.in_scale = in_scale; a.act = act; a.act_param = act_param; a.act_aux = act_aux;
     a.vec = (T % 4 == 0) ? 1 : 0;
-    static const int dbg = getenv("EEGGAN_DEBUG") ? atoi(getenv("EEGGAN_DEBUG")) : 0;
-    a.debug = dbg;
     a.wpb = 0;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);

@@ -356,8 +356,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 template <int K, bool MASKED, bool FULL>
 int launch_rm(const ConvArgs& a, hipStream_t st) {
     // whole-subtile units once every SIMD has at least two of them to interleave, half units below
-    static const int force = getenv("EEGGAN_WS_RM") ? atoi(getenv("EEGGAN_WS_RM")) : 0;  // timing experiments only
-    const bool halves = force ? force == 1 : a.NS < 8 * num_cus();
+    const bool halves = a.NS < 8 * num_cus();
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
 

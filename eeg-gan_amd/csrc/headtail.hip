@@ -357,8 +357,7 @@ extern "C" int eeggan_head_fwd(const float* z, const float* w, const float* bias
     if (check_ht("head_fwd", B, Cin, Cout, KT)) return 1;
     EEGGAN_REQUIRE(z && w && y, "head_fwd: null pointer");
     EEGGAN_REQUIRE(Cin <= 384, "head_fwd: Cin %d above the supported 384 (LDS tile)", Cin);
-    static const bool valu_only = getenv("EEGGAN_HEAD_VALU") != nullptr;  // comparison runs only
-    if (KT == 32 && Cin % 64 == 0 && !valu_only)
+    if (KT == 32 && Cin % 64 == 0)
         hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3(Cout, (B + 31) / 32), dim3(256),
                            (size_t)(32 * (Cin + 1) + 4 * 32 * 33) * sizeof(float), as_stream(stream), z, w, bias, drop,
                            y, B, Cin, Cout, in_scale, act, act_param);

@@ -131,3 +131,43 @@ def test_adam_descriptor_table_layout():
     raw = bytes(arr)
     assert raw[40:48] == (6).to_bytes(8, "little") and raw[48:56] == (7).to_bytes(8, "little")
     assert raw[88:96] == (12).to_bytes(8, "little")
+
+
+def test_trainer_plugin_schedule():
+    """Plugin firing rule of the reference (trainer.py:39-60): a plugin fires when its next time is
+    due, earliest first and in registration order among equals, and is re-armed one period after the
+    time it fired at."""
+    from eeggan_amd.plugins import Plugin
+    from eeggan_amd.trainer import Trainer
+
+    calls = []
+
+    class P(Plugin):
+        def __init__(self, name, interval):
+            super().__init__(interval)
+            self.name = name
+
+        def register(self, trainer):
+            self.trainer = trainer
+
+        def iteration(self, time, *args):
+            calls.append((self.name, time, args))
+
+        def epoch(self, time, *args):
+            calls.append((self.name + "/tick", time, args))
+
+    tr = Trainer(None, None, None, None, None, iter(()), 0, None, None)
+    a, b, c = P("a", [(1, "iteration")]), P("b", [(2, "iteration"), (1, "epoch")]), P("c", (3, "iteration"))
+    for p in (a, b, c):
+        tr.register_plugin(p)
+    assert a.trainer is tr
+    for it in range(1, 7):
+        tr.call_plugins("iteration", it, "g", "d")
+    fired = [(n, t) for n, t, _ in calls]
+    assert fired == [("a", 1), ("a", 2), ("b", 2), ("a", 3), ("c", 3), ("a", 4), ("b", 4), ("a", 5), ("a", 6), ("b", 6),
+                     ("c", 6)]
+    assert calls[0][2] == ("g", "d")
+    calls.clear()
+    tr.call_plugins("epoch", 1)
+    tr.call_plugins("end", 1)  # nobody registered: no-op
+    assert [(n, t) for n, t, _ in calls] == [("b/tick", 1)]
