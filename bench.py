@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying HIP graphs")
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--alpha", type=float, default=ALPHA, help="fade-in factor (< 1: mid-transition step)")
     return ap.parse_args()
 
 
@@ -168,7 +169,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     from eeggan_amd import layers
     layers.set_drop_mode(args.drop_mode)
-    tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank, args.eager)
+    tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager)
 
     def barrier():
         if dist is not None:
@@ -182,7 +183,7 @@ def main():
             raise
         print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
         torch.cuda.synchronize()
-        tr = make_trainer(dev, args.depth, ALPHA, args.batch, 1373, world, rank, eager=True)
+        tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, eager=True)
     for _ in range(args.warmup):
         tr.train()
     barrier()
@@ -203,14 +204,14 @@ def main():
             "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha=1, 5 D + 1 G iterations "
+            "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha={args.alpha:g}, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
                        "parallelism": f"dp{world}", "drop_noise": args.drop_mode,
                        "launch": type(tr).__name__},
         }
         out["roofline"] = conv_roofline(dev, args.batch, T)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.depth, ALPHA, args.batch, 1373)
+            out["cpu_baseline"] = cpu_baseline(args.depth, args.alpha, args.batch, 1373)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

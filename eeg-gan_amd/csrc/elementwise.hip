@@ -194,10 +194,19 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     }
 }
 
+// out = ca*a + cb*b.  `alpha` != nullptr: the coefficients come from the fade-in factor in device
+// memory (mode 0: ca = alpha, cb = 1 - alpha; 1: ca = alpha; 2: ca = 1 - alpha) -- the same loop body as
+// the by-value form, so both give bit-identical results for equal coefficients.
 template <bool VEC, bool HASB>
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, float ca, const float* __restrict__ b,
-                                                    float cb, float* __restrict__ out, size_t n) {
+                                                    float cb, float* __restrict__ out, size_t n,
+                                                    const float* __restrict__ alpha, int mode) {
     constexpr int W = VEC ? 4 : 1;
+    if (alpha) {
+        const float al = alpha[0];
+        ca = mode == 2 ? 1.f - al : al;
+        cb = 1.f - al;
+    }
     const size_t items = n / W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         if (VEC) {
@@ -309,18 +318,43 @@ extern "C" int eeggan_axpby(const float* a, float ca, const float* b, float cb, 
     if (vec) {
         if (b)
             hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb, out,
-                               n);
+                               n, nullptr, 0);
         else
             hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb,
-                               out, n);
+                               out, n, nullptr, 0);
     } else {
         if (b)
-            hipLaunchKernelGGL((axpby_kernel<false, true>), dim3(blocks_for(n)), dim3(256), 0, st, a, ca, b, cb, out, n);
+            hipLaunchKernelGGL((axpby_kernel<false, true>), dim3(blocks_for(n)), dim3(256), 0, st, a, ca, b, cb, out, n, nullptr, 0);
         else
             hipLaunchKernelGGL((axpby_kernel<false, false>), dim3(blocks_for(n)), dim3(256), 0, st, a, ca, b, cb, out,
-                               n);
+                               n, nullptr, 0);
     }
     return check_launch("axpby");
+}
+
+extern "C" int eeggan_blend(const float* a, const float* b, const float* alpha, int mode, float* out, size_t n,
+                            void* stream) {
+    EEGGAN_REQUIRE(a && alpha && out && n > 0, "blend: null pointer or empty");
+    EEGGAN_REQUIRE(mode >= 0 && mode <= 2 && (mode != 0 || b), "blend: mode %d (0 needs b)", mode);
+    if (mode != 0) b = nullptr;
+    const bool vec = (n % 4 == 0) && aligned16(a) && aligned16(out) && (!b || aligned16(b));
+    hipStream_t st = as_stream(stream);
+    if (vec) {
+        if (b)
+            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f, out,
+                               n, alpha, mode);
+        else
+            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f,
+                               out, n, alpha, mode);
+    } else {
+        if (b)
+            hipLaunchKernelGGL((axpby_kernel<false, true>), dim3(blocks_for(n)), dim3(256), 0, st, a, 0.f, b, 0.f, out, n,
+                               alpha, mode);
+        else
+            hipLaunchKernelGGL((axpby_kernel<false, false>), dim3(blocks_for(n)), dim3(256), 0, st, a, 0.f, b, 0.f, out,
+                               n, alpha, mode);
+    }
+    return check_launch("blend");
 }
 
 extern "C" int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out, int B, size_t per,

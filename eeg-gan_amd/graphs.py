@@ -75,8 +75,9 @@ class GraphedTrainer(Trainer):
 
     Graphs are (re)captured whenever (depth, alpha, batch shape, optimizers) change; the warm-up
     runs needed for capture are undone (parameters and optimizer state are restored), so the
-    sequence of updates equals the eager trainer's.  While alpha < 1 (fade-in) alpha changes at
-    every iteration and is a kernel argument, so those iterations run eagerly.  Requires the
+    sequence of updates equals the eager trainer's.  During fade-in (alpha < 1) the factor is read
+    by the blend kernels from a one-element device tensor that is refreshed before every step, so
+    the same graphs serve the whole transition.  Requires the
     device noise mode (``layers.set_drop_mode('device')``): host RNG draws cannot be captured.
 
     With a data-parallel ``grad_sync`` (``parallel.DataParallelStep``) every iteration is two
@@ -126,6 +127,16 @@ class GraphedTrainer(Trainer):
         _restore(snap)
         self._key = key
 
+    def _sync_alpha(self):
+        """The fade-in factor is a kernel operand read from device memory: refresh it before the
+        replays of this step (the depth manager moves it between steps, reference plugins.py:115-117)."""
+        for net in (self.generator, self.discriminator):
+            if net.alpha < 1.0:
+                if net.alpha_dev is None:
+                    net.alpha_dev = torch.empty(1, device=next(net.parameters()).device, dtype=torch.float32)
+                net.alpha_dev.fill_(float(net.alpha))
+            # (at alpha == 1 the networks take the branch without a blend and never read alpha_dev)
+
     def _replay(self, parts):
         first, bucket, second = parts
         loss = first()
@@ -137,14 +148,18 @@ class GraphedTrainer(Trainer):
 
     def train(self):
         gen, dis = self.generator, self.discriminator
-        if gen.alpha != 1.0 or self.lr_scheduler_d is not None or self.lr_scheduler_g is not None:
+        if self.lr_scheduler_d is not None or self.lr_scheduler_g is not None:
             self._key = None
+            for net in (gen, dis):
+                net.alpha_dev = None
             return super().train()
+        self._sync_alpha()
         z = cudize(next(self.random_latents_generator))["z"]
         d_loss = None
         for _ in range(self.d_training_repeats):
             real = cudize(next(self.dataiter))["x"]
-            key = (gen.depth, tuple(real.shape), tuple(z.shape), id(self.optimizer_d), id(self.optimizer_g),
+            key = (gen.depth, gen.alpha < 1.0, dis.alpha < 1.0, tuple(real.shape), tuple(z.shape),
+                   id(self.optimizer_d), id(self.optimizer_g),
                    self.optimizer_d.param_groups[0]["lr"], self.optimizer_g.param_groups[0]["lr"])
             if key != self._key:
                 self._capture(real, z, key)

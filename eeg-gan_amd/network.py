@@ -71,6 +71,8 @@ class Generator(nn.Module):
         self.progression_scale_down = progression_scale_down
         self.depth = 0
         self.alpha = 1.0
+        # optional one-element device tensor mirroring alpha (kept current by graphs.GraphedTrainer)
+        self.alpha_dev = None
         self.split_z = False
         self.z_distribution = z_distribution
         self.conv_only = False
@@ -120,7 +122,8 @@ class Generator(nn.Module):
         if self.alpha == 1.0:
             return {"x": ult, "y": None}, {}
         prev = self.blocks[d - 2] if d > 1 else self.block0
-        return {"x": ops.axpby(prev.to_rgb(h), 1.0 - self.alpha, ult, self.alpha), "y": None}, {}
+        alpha = self.alpha_dev if self.alpha_dev is not None else self.alpha
+        return {"x": ops.blend(ult, prev.to_rgb(h), alpha), "y": None}, {}
 
 
 class DBlock(nn.Module):
@@ -168,6 +171,8 @@ class Discriminator(nn.Module):
         self.progression_scale_down = progression_scale_down
         self.depth = 0
         self.alpha = 1.0
+        # optional one-element device tensor mirroring alpha (kept current by graphs.GraphedTrainer)
+        self.alpha_dev = None
         self.input_to_all_layers = False
 
         def nf(stage):
@@ -206,7 +211,7 @@ class Discriminator(nn.Module):
             h = self._shrink(h, d - 1)
             if self.alpha < 1.0:
                 low = self.blocks[-d].from_rgb(self._shrink(x, d - 1))
-                h = ops.axpby(h, self.alpha, low, 1.0 - self.alpha)
+                h = ops.blend(h, low, self.alpha_dev if self.alpha_dev is not None else self.alpha)
         for i in range(d, 0, -1):
             h = self.blocks[-i](h)
             if i > 1:

@@ -19,6 +19,7 @@ import os
 import weakref
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -672,6 +673,56 @@ class _Axpby(Function):
 def axpby(a, ca, b, cb):
     """ca*a + cb*b (fade-in blends)."""
     return _Axpby.apply(a, b, float(ca), float(cb))
+
+
+def _blend_raw(a, b, alpha, mode):
+    a = _chk(a, "blend a")
+    if b is not None:
+        b = _chk(b, "blend b")
+        if b.shape != a.shape:
+            raise RuntimeError(f"blend: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    if alpha.numel() != 1 or alpha.dtype != torch.float32 or alpha.device != a.device:
+        raise RuntimeError("blend: alpha must be a one-element float32 tensor on the operands' device")
+    out = torch.empty_like(a)
+    call("eeggan_blend", a.data_ptr(), _p(b), alpha.data_ptr(), int(mode), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+class _ScaleDev(Function):
+    """alpha*x (mode 1) or (1-alpha)*x (mode 2) with alpha in device memory; linear, so its own backward."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, mode):
+        ctx.alpha, ctx.mode = alpha, mode
+        return _blend_raw(x, None, alpha, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScaleDev.apply(g, ctx.alpha, ctx.mode), None, None
+
+
+class _BlendDev(Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = alpha
+        return _blend_raw(a, b, alpha, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = _ScaleDev.apply(g, ctx.alpha, 1) if ctx.needs_input_grad[0] else None
+        gb = _ScaleDev.apply(g, ctx.alpha, 2) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+def blend(a, b, alpha):
+    """alpha*a + (1-alpha)*b.  ``alpha`` is a Python float or a one-element device tensor; the latter
+    is read by the kernel at run time, so a captured graph follows a fade-in factor that changes."""
+    if torch.is_tensor(alpha):
+        return _BlendDev.apply(a, b, alpha)
+    # same float32 arithmetic as the device-alpha kernel (1 - alpha rounded in float32), so that both
+    # routes give bit-identical blends
+    al = np.float32(alpha)
+    return _Axpby.apply(a, b, float(al), float(np.float32(1.0) - al))
 
 
 # --------------------------------------------------------------------------------------- minibatch stddev

@@ -137,6 +137,11 @@ int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop
 int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_t n, float scale, void* stream);
 /* out = ca*a + cb*b (b may be NULL: out = ca*a).  Fade-in blends network.py:393-396,533-540. */
 int eeggan_axpby(const float* a, float ca, const float* b, float cb, float* out, size_t n, void* stream);
+/* The same blends with the fade-in factor read from DEVICE memory (alpha[0]), so that a captured
+ * launch follows the factor the depth manager updates at every iteration (plugins.py:115-117):
+ *   mode 0: out = alpha*a + (1-alpha)*b;  mode 1: out = alpha*a;  mode 2: out = (1-alpha)*a  (b unused). */
+int eeggan_blend(const float* a, const float* b, const float* alpha, int mode, float* out, size_t n,
+                 void* stream);
 /* out[b,:] = mix[b]*real[b,:] + (1-mix[b])*fake[b,:]  (losses.py:107-108); per = C*T. */
 int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out,
                      int B, size_t per, void* stream);

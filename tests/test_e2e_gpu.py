@@ -278,7 +278,7 @@ def test_full_step_fixture(dev):
             assert e < tol, f"{net}.{k}: update differs by {e:.3e} (tolerance {tol:.3e})"
 
 
-def _two_steps(dev, cls, sync_factory=None, lr=0.002):
+def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0)):
     """Two training steps at depth 2 with the noise off and fixed mixing factors (so that every
     variant sees the same random inputs).  Returns the weights, Adam's moments and step counts."""
     from eeggan_amd import config
@@ -308,8 +308,9 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002):
     tr.dataiter = iter([{"x": r} for r in reals])
     if sync_factory is not None:
         tr.grad_sync = sync_factory()
-    tr.train()
-    tr.train()
+    for alpha in alphas:  # what the depth manager does between steps during a transition
+        g.alpha = d.alpha = alpha
+        tr.train()
     torch.cuda.synchronize()
     out = {}
     for tag, net, opt in (("G", g, opt_g), ("D", d, opt_d)):
@@ -322,7 +323,7 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002):
     return out
 
 
-def _same_trajectory(base, other, what):
+def _same_trajectory(base, other, what, moment_tol=1e-5):
     """The accumulation order of the three gradient contributions of a critic weight is up to the
     autograd engine (nodes made during the double backward are numbered by another thread), so two
     runs of the same eager code already differ by an ulp in some gradients, and Adam with beta1 = 0
@@ -344,7 +345,7 @@ def _same_trajectory(base, other, what):
             assert torch.equal(a, b), f"{what}: {k} differs with lr = 0"
         else:
             err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-30)
-            assert err < 1e-5, f"{what}: {k} differs by {err:.2e} of its scale with lr = 0"
+            assert err < moment_tol, f"{what}: {k} differs by {err:.2e} of its scale with lr = 0"
     moved = 0
     for k, a in live_a.items():
         if k.endswith((".m", ".v", ".step")):
@@ -386,6 +387,26 @@ def test_graph_replay_equals_eager(dev):
         layers.set_drop_mode("numpy")
     _same_trajectory(base, direct, "side-stream weight gradients")
     _same_trajectory(base, graphed, "graph replay")
+
+
+def test_graph_replay_during_fade_in(dev):
+    """With alpha moving from step to step (0.3 then 0.6) the captured graphs, which read alpha from
+    device memory, follow the eager trainer, whose kernels get it as an argument."""
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    fade = (0.3, 0.6)
+    try:
+        base = _two_steps(dev, Trainer, lr=0.0, alphas=fade), _two_steps(dev, Trainer, alphas=fade)
+        graphed = _two_steps(dev, GraphedTrainer, lr=0.0, alphas=fade), _two_steps(dev, GraphedTrainer, alphas=fade)
+        constant = _two_steps(dev, GraphedTrainer, lr=0.0, alphas=(0.3, 0.3))
+    finally:
+        layers.set_drop_mode("numpy")
+    _same_trajectory(base, graphed, "graph replay during fade-in")
+    # the second step really used the new alpha: the last gradients differ from a run that kept 0.3
+    k = next(k for k in graphed[0] if k.startswith("D.") and k.endswith(".m"))
+    assert not torch.equal(graphed[0][k], constant[k])
 
 
 def test_data_parallel_graphs_equal_eager(dev):
