@@ -477,3 +477,75 @@ def test_stacked_critic_pass_equals_sequential(dev):
     for k in g0:
         e = float((g0[k] - g1[k]).norm()) / max(float(g0[k].norm()) + term[k], 1e-30)
         assert e < 2e-2, f"{k}: stacked pass differs by {e:.2e} of the real term's scale"
+
+
+def test_progressive_schedule_with_graphs(dev):
+    """DepthManager (the reference's plugins.py:78-119 schedule) driving the graph trainer through a
+    stable stage, a fade-in and the next stable stage: depth/alpha/optimizers/minibatch change under
+    the trainer's feet and it has to re-capture; alpha during the fade comes from device memory."""
+    from eeggan_amd import config, layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.optim import Adam
+    from eeggan_amd.plugins import DepthManager, Plugin
+
+    class SmallStages(DepthManager):
+        minibatch_override = {0: 8, 1: 8}
+        tick_kimg_override = {}
+        training_kimg_override = {}
+        transition_kimg_override = {}
+
+    class Dataset:
+        model_depth, alpha = 0, 1.0
+
+    class Watch(Plugin):
+        def __init__(self):
+            super().__init__([(1, "iteration")])
+            self.seen = []
+
+        def register(self, trainer):
+            self.trainer = trainer
+
+        def iteration(self, time, g_loss, d_loss):
+            tr = self.trainer
+            self.seen.append((tr.generator.depth, tr.generator.alpha, float(g_loss), float(d_loss), tr._key))
+
+    layers.set_drop_mode("device")
+    try:
+        g, d = config.build_models(3)
+        g, d = g.to(dev), d.to(dev)
+        ds = Dataset()
+        gen = torch.Generator(device=dev).manual_seed(1)
+
+        def loader(minibatch):
+            T = config.seq_len(ds.model_depth)
+            while True:
+                yield {"x": torch.randn(minibatch, 5, T, device=dev, generator=gen)}
+
+        def latents(minibatch):
+            while True:
+                yield {"z": torch.randn(minibatch, 256, device=dev, generator=gen)}
+
+        def optimizers(lr):
+            return Adam(g.parameters(), lr, **config.ADAM), Adam(d.parameters(), lr, **config.ADAM), None, None
+
+        d_loss, g_loss = config.loss_closures()
+        tr = GraphedTrainer(d, g, d_loss, g_loss, ds, None, 0, None, None, tick_kimg_default=0.04)
+        # 80 reals stable at depth 0, 160 reals of fade-in, then depth 1 stable (40 reals per step)
+        tr.register_plugin(SmallStages(loader, latents, 1, 0.04, optimizers, 0.001, lod_training_kimg=0.08,
+                                       lod_transition_kimg=0.16))
+        watch = Watch()
+        tr.register_plugin(watch)
+        start = {k: v.clone() for k, v in g.state_dict().items()}
+        tr.run(total_kimg=0.36)
+    finally:
+        layers.set_drop_mode("numpy")
+    depths = [s[0] for s in watch.seen]
+    alphas = [s[1] for s in watch.seen]
+    assert depths == [0, 0] + [1] * 7
+    # (the watcher runs after the depth manager, so it sees the settings of the NEXT step)
+    assert alphas == [1.0, 1.0, 0.25, 0.5, 0.75, 1.0, 1.0, 1.0, 1.0]
+    assert all(np.isfinite(s[2]) and np.isfinite(s[3]) for s in watch.seen)
+    assert len({s[4] for s in watch.seen}) == 3, "one capture per (depth, fading?) phase"
+    assert all(torch.isfinite(v).all() for v in g.state_dict().values())
+    assert any(not torch.equal(v, start[k]) for k, v in g.state_dict().items())
+    assert tr.cur_tick >= 8
