@@ -238,6 +238,25 @@ def resample(x, signal_freq: int, desired_freq: int):
     return x
 
 
+def datapoint_from_depth(x, target_depth: int, cfg: "NetConfig" = None):
+    """dataset.py:169-173: a full-rate window [B, C, T_max] taken down to stage ``target_depth``
+    one stage transition at a time (ratio scale_down/scale_up of that transition)."""
+    cfg = cfg or NetConfig()
+    for index in range(len(cfg.scale_up) - 1, target_depth - 1, -1):
+        x = resample(x, cfg.scale_up[index], cfg.scale_down[index])
+    return x
+
+
+def alpha_fade_reals(x, depth: int, alpha: float, cfg: "NetConfig" = None):
+    """dataset.py:175-180: x + (t - x) * (1 - alpha), t = x taken down one stage and back up."""
+    cfg = cfg or NetConfig()
+    if alpha == 1:
+        return x
+    up, down = cfg.scale_up[depth - 1], cfg.scale_down[depth - 1]
+    t = resample(resample(x, up, down), down, up)
+    return x + (t - x) * (1 - alpha)
+
+
 def minibatch_stddev(x, group_size: int = 4, window: int = 32):
     """layers.py:74-90 with temporal_groups_per_window=1: per window of
     ``window`` time steps, samples are split into ``G=min(B, group_size)``

@@ -329,3 +329,30 @@ def test_per_op_golden(dev):
     y = ops.conv1d_raw(t("tanh_c"), torch.eye(5, device=dev)[:, :, None].contiguous(), None, None, act=2,
                        act_param=0.5)
     assert rel(y, fx["tanh_y"]) < TOL
+
+
+def test_real_data_side_on_device(dev):
+    """DepthResampler (the device form of the reference dataset's per-sample resampling and fade,
+    dataset.py:161-187) against the reference's own outputs for the same windows; the resampling
+    tables reproduce ATen's float32 interpolation weights, hence the tight bar."""
+    from eeggan_amd import config
+    from eeggan_amd.dataset import DepthResampler
+    fx = load_fixture("dataset_ops")
+    w = torch.from_numpy(fx["windows"]).to(dev)
+    rs = DepthResampler(config.PROGRESSION_SCALE_UP, config.PROGRESSION_SCALE_DOWN)
+    checked = 0
+    for depth in range(8):
+        for alpha in (1.0, 0.3):
+            key = f"x_d{depth}_a{alpha:g}"
+            if key not in fx:
+                continue
+            rs.model_depth, rs.alpha = depth, alpha
+            got = rs(w)["x"]
+            assert tuple(got.shape) == fx[key].shape
+            e = rel(got, fx[key])
+            assert e < 1e-5, (key, e)
+            checked += 1
+    assert checked == 15
+    rs.model_depth, rs.alpha = 0, 0.5
+    with pytest.raises(ValueError):
+        rs(w)

@@ -85,3 +85,21 @@ def test_schedule_matches_reference_description():
     cfg = O.NetConfig()
     assert [cfg.seq_len(d) for d in range(8)] == [32, 128, 256, 512, 768, 1024, 1280, 1920]
     assert [cfg.nf(s) for s in range(9)] == [256, 256, 256, 128, 64, 64, 64, 64, 64]
+
+
+def test_real_data_side_matches_reference_dataset():
+    """Oracle restatement of EEGDataset.create_datapoint_from_depth / alpha_fade (dataset.py:161-187)
+    against what the reference's __getitem__ returned for the same windows.  The reference runs in
+    float32 (ATen's interpolation weights alone carry ~1.5e-5 per transition), the oracle in float64."""
+    fx = load_fixture("dataset_ops")
+    w = torch.from_numpy(fx["windows"]).double()
+    worst = 0.0
+    for depth in range(8):
+        for alpha in (1.0, 0.3):
+            key = f"x_d{depth}_a{alpha:g}"
+            if key not in fx:
+                continue
+            got = O.alpha_fade_reals(O.datapoint_from_depth(w, depth), depth, alpha)
+            assert tuple(got.shape) == fx[key].shape == (3, 5, O.NetConfig().seq_len(depth))
+            worst = max(worst, rel(got, fx[key]))
+    assert worst < 1e-4, worst

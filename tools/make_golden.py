@@ -410,6 +410,39 @@ def step_fixture(out_dir, seed=11):
     print("step_depth0.npz: losses", [f"{x:.5f}" for x in l64])
 
 
+def dataset_fixture(out_dir):
+    """The reference's EEGDataset.__getitem__ (dataset.py:161-187) on a synthetic recording, at every
+    stage and at two fade-in factors; inputs are the windows its load_file cuts (same host RNG)."""
+    sys.path.insert(0, REF)
+    import dataset as ref_dataset  # noqa
+    sys.path.remove(REF)
+    rng = np.random.default_rng(7)
+    stride = 2880
+    recording = rng.standard_normal((5, stride * 3)).astype(np.float32)
+    recording = np.cumsum(recording, axis=1) * 0.05  # smooth-ish, EEG-like drift
+    recording = (recording / np.abs(recording).max()).astype(np.float32)
+    ds = ref_dataset.EEGDataset([[(0, 0), (0, 1), (0, 2)], [recording]])
+    assert ds.seq_len == 1920 and ds.stride == stride
+    fx = {"seed": np.array(11)}
+    np.random.seed(11)
+    windows = np.stack([ds.load_file(i) for i in range(3)])
+    fx["windows"] = windows
+    for depth in range(0, 8):
+        for alpha in (1.0, 0.3):
+            if alpha != 1.0 and depth == 0:
+                continue
+            ds.model_depth, ds.alpha = depth, alpha
+            np.random.seed(11)
+            out = torch.stack([ds[i]["x"] for i in range(3)])
+            fx[f"x_d{depth}_a{alpha:g}"] = out.numpy()
+            # oracle (fp64) pinned against the reference's float32 arithmetic
+            ref = O.alpha_fade_reals(O.datapoint_from_depth(torch.from_numpy(windows).double(), depth), depth, alpha)
+            err = rel(ref, out)
+            assert ref.shape == out.shape and err < 2e-4, (depth, alpha, err)
+    np.savez_compressed(os.path.join(out_dir, "dataset_ops.npz"), **fx)
+    print("dataset_ops.npz:", len(fx), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -425,6 +458,7 @@ def main():
         "e2e_d7": lambda: e2e_fixture(args.out, "e2e_d7_a1", 7, 1.0, 4, 104),
         "e2e_d7f": lambda: e2e_fixture(args.out, "e2e_d7_a05", 7, 0.5, 4, 105),
         "step": lambda: step_fixture(args.out),
+        "dataset": lambda: dataset_fixture(args.out),
     }
     for k, fn in jobs.items():
         if not args.only or k in args.only.split(","):
