@@ -29,6 +29,8 @@ SIGNATURES = {
     "eeggan_last_error": (C.c_char_p, []),
     "eeggan_abi_version": (_i, []),
     "eeggan_conv1d": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _fl, _f, _f, _f, _fl, _st]),
+    "eeggan_conv1d_pixelnorm_supported": (_i, [_i, _i, _i, _i, _i]),
+    "eeggan_conv1d_pixelnorm": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _fl, _st]),
     "eeggan_conv1d_flip_weights": (_i, [_f, _f, _i, _i, _i, _st]),
     "eeggan_conv1d_flip_weights_multi": (_i, [C.c_void_p, _i, _st]),
     "eeggan_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),

@@ -21,6 +21,8 @@ struct ConvArgs {
     float act_param;
     const float* act_aux;
     int vec;  // T % 4 == 0: 16-byte global loads are aligned
+    float* pn_d;   // ACT_LRELU_PN: per-(sample, time) normaliser output [B, T]
+    float pn_eps;
     int wpb;    // weight-stationary kernel: waves per workgroup that take work units
 #ifdef EEGGAN_TRACE
     unsigned long long* trace;  // [4 traced blocks][8 waves][TRACE_STEPS][8] shader-clock stamps
@@ -42,9 +44,14 @@ constexpr int TRACE_STEPS = 16;
     } while (0)
 #endif
 
+// Internal epilogue code of the weight-stationary kernel: LeakyReLU, then PixelNorm over the output
+// channels (all of them live in one work unit), then the multiplier.
+constexpr int ACT_LRELU_PN = 4;
+
 // Weight-stationary variant for layers with at most 64 input and 64 output channels (conv_ws.hip).
 // Returns -1 when the shape is not covered, otherwise the launch status.
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st);
+bool conv_ws_covers(const ConvArgs& a, int K);
 int num_cus();
 
 }  // namespace eeggan

@@ -974,8 +974,40 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     a.in_scale = in_scale; a.act = act; a.act_param = act_param; a.act_aux = act_aux;
     a.vec = (T % 4 == 0) ? 1 : 0;
     a.wpb = 0;
+    a.pn_d = nullptr;
+    a.pn_eps = 0.f;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
+}
+
+extern "C" int eeggan_conv1d_pixelnorm_supported(int B, int Cin, int Cout, int T, int K) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0) return 0;
+    ConvArgs a{};
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
+    a.ST = (T + 31) / 32;
+    a.NS = B * a.ST;
+    return conv_ws_covers(a, K) ? 1 : 0;
+}
+
+extern "C" int eeggan_conv1d_pixelnorm(const float* x, const float* w, const float* bias, const float* drop, float* y,
+                                       float* d, int B, int Cin, int Cout, int T, int K, float in_scale, float slope,
+                                       float eps, void* stream) {
+    if (check_common(B, Cin, Cout, T, K)) return 1;
+    EEGGAN_REQUIRE(x && w && y && d, "conv1d_pixelnorm: null x/w/y/d pointer");
+    EEGGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0,
+                   "conv1d_pixelnorm: x, w, y and d must be 16-byte aligned");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.drop = drop; a.y = y;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.T = T;
+    a.ST = (T + 31) / 32;
+    a.NS = B * a.ST;
+    a.in_scale = in_scale; a.act = ACT_LRELU_PN; a.act_param = slope;
+    a.vec = (T % 4 == 0) ? 1 : 0;
+    a.pn_d = d; a.pn_eps = eps;
+    EEGGAN_REQUIRE(conv_ws_covers(a, K), "conv1d_pixelnorm: shape B=%d Cin=%d Cout=%d T=%d K=%d is not covered "
+                   "(see eeggan_conv1d_pixelnorm_supported)", B, Cin, Cout, T, K);
+    return launch_conv_ws(a, K, as_stream(stream));
 }
 
 extern "C" int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, void* stream) {

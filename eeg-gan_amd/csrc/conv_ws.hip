@@ -292,6 +292,48 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                         *reinterpret_cast<const f32x4*>(ok ? ab + ylo + 8 * i * a.T : a.act_aux);
                 }
             }
+            if (ACT == ACT_LRELU_PN) {
+                // PixelNorm over the channel axis: this lane holds rows r0 + 8 i of four time steps; the
+                // other rows of the same time steps sit in the lanes that differ in lane bits 3..5
+                f32x4 vals[NE];
+                float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int row = r0 + 8 * i;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(E + row * EL + 4 * q);
+                    const float bias_v = has_bias ? bb[i] : 0.f;
+                    const bool rok = FULL || co_base + row < a.Cout;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = v[e] + bias_v;
+                        t = t > 0.f ? t : t * a.act_param;
+                        t = rok ? t : 0.f;
+                        vals[i][e] = t;
+                        ss[e] += t * t;
+                    }
+                }
+                f32x4 dv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = ss[e];
+                    s += __shfl_xor(s, 8, 64);
+                    s += __shfl_xor(s, 16, 64);
+                    s += __shfl_xor(s, 32, 64);
+                    dv[e] = rsqrtf(s / (float)a.Cout + a.pn_eps);
+                }
+                if (r0 == 0 && st_ok) *reinterpret_cast<f32x4*>(a.pn_d + (long long)cur.b * a.T + cur.t0 + 4 * q) = dv;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const int row = r0 + 8 * i;
+                    const float drop_v = has_drop ? dd[i] : 1.f;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = vals[i][e] * dv[e] * drop_v;
+                    if (FULL || (st_ok && co_base + row < a.Cout))
+                        *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const int row = r0 + 8 * i;  // row of the unit's tile; output channel co_base + row
@@ -313,6 +355,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             case EEGGAN_ACT_LRELU: run(std::integral_constant<int, EEGGAN_ACT_LRELU>{}); break;
             case EEGGAN_ACT_TANH: run(std::integral_constant<int, EEGGAN_ACT_TANH>{}); break;
             case EEGGAN_ACT_MASK: run(std::integral_constant<int, EEGGAN_ACT_MASK>{}); break;
+            case ACT_LRELU_PN:
+                if (RM == 2) run(std::integral_constant<int, (RM == 2 ? ACT_LRELU_PN : EEGGAN_ACT_NONE)>{});
+                break;
             default: run(std::integral_constant<int, EEGGAN_ACT_NONE>{}); break;
         }
         EEGGAN_STAMP(step, 3);
@@ -356,15 +401,19 @@ int launch(const ConvArgs& a, hipStream_t st) {
 template <int K, bool MASKED, bool FULL>
 int launch_rm(const ConvArgs& a, hipStream_t st) {
     // whole-subtile units once every SIMD has at least two of them to interleave, half units below
-    const bool halves = a.NS < 8 * num_cus();
+    const bool halves = a.act != ACT_LRELU_PN && a.NS < 8 * num_cus();  // (the norm needs all channels in one unit)
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
 
 }  // namespace
 
+bool conv_ws_covers(const ConvArgs& a, int K) {
+    if (K != 3 || a.Cin > 64 || a.Cout > 64 || a.Cout <= 32 || a.T % 4 != 0 || a.NS < 256) return false;
+    return (long long)a.Cin * a.T * 2 < (1ll << 31) && (long long)a.Cout * a.T * 2 < (1ll << 31);
+}
+
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st) {
-    if (K != 3 || a.Cin > 64 || a.Cout > 64 || a.Cout <= 32 || a.T % 4 != 0 || a.NS < 256) return -1;
-    if ((long long)a.Cin * a.T * 2 >= (1ll << 31) || (long long)a.Cout * a.T * 2 >= (1ll << 31)) return -1;
+    if (!conv_ws_covers(a, K)) return -1;
     const bool full = a.Cin == 64 && a.Cout == 64 && a.T % 32 == 0;
     if (a.mask_y) return full ? launch_rm<3, true, true>(a, st) : launch_rm<3, true, false>(a, st);
     return full ? launch_rm<3, false, true>(a, st) : launch_rm<3, false, false>(a, st);

@@ -157,6 +157,22 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
     return y
 
 
+def conv1d_pixelnorm_raw(x, w, bias, drop, *, in_scale, slope, eps=1e-8):
+    """(y, d) of the fused conv + LeakyReLU + PixelNorm + multiplier kernel, or None when the shape is
+    not covered (the caller then runs the conv and the norm as two kernels)."""
+    x = _chk(x, "conv1d x")
+    w = _chk(w, "conv1d w")
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    if w.shape[1] != Cin or not _lib.load().eeggan_conv1d_pixelnorm_supported(B, Cin, Cout, T, K):
+        return None
+    y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    d = torch.empty((B, T), device=x.device, dtype=torch.float32)
+    call("eeggan_conv1d_pixelnorm", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), d.data_ptr(), B, Cin,
+         Cout, T, K, float(in_scale), float(slope), float(eps), _stream())
+    return y, d
+
+
 def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mask_drop=None, mask_slope=0.0,
                      out_w=None, out_b=None, beta_w=0.0, beta_b=0.0):
     """Weight/bias gradient.  ``out_w``/``out_b``: write into these buffers instead of new tensors,
@@ -550,8 +566,12 @@ class _GLayer(Function):
                  float(in_scale), ACT_LRELU, float(slope), _stream())
             y, d = pixelnorm_drop_fwd_raw(h, drop)
         elif mode == "pn":
-            h = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_LRELU, act_param=slope)
-            y, d = pixelnorm_drop_fwd_raw(h, drop)
+            fused = conv1d_pixelnorm_raw(x, w, bias, drop, in_scale=in_scale, slope=slope)
+            if fused is not None:
+                y, d = fused
+            else:
+                h = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_LRELU, act_param=slope)
+                y, d = pixelnorm_drop_fwd_raw(h, drop)
         elif mode == "tanh":
             y = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_TANH, act_param=tanh_scale)
         else:

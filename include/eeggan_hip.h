@@ -56,6 +56,15 @@ int eeggan_conv1d(const float* x, const float* w, const float* bias, const float
                   const float* mask_y, const float* mask_drop, float mask_slope,
                   void* stream);
 int eeggan_conv1d_flip_weights(const float* w, float* wt, int Cout, int Cin, int K, void* stream);
+/* The generator's layer in one kernel (GeneralConv.forward with act_norm='pixel', layers.py:196-213):
+ *   h = lrelu(bias + conv(in_scale*x, w));  d[b,t] = rsqrt(mean_co h^2 + eps);  y = drop * h * d
+ * y [B,Cout,T] and the normaliser d [B,T] (what eeggan_pixelnorm_drop_bwd needs) are written; h is not.
+ * Only for shapes whose output channels all fit one work unit of the weight-stationary kernel
+ * (K = 3, Cin <= 64, 32 < Cout <= 64, T % 4 == 0, B*ceil(T/32) >= 256): ask _supported first. */
+int eeggan_conv1d_pixelnorm_supported(int B, int Cin, int Cout, int T, int K);
+int eeggan_conv1d_pixelnorm(const float* x, const float* w, const float* bias, const float* drop,
+                            float* y, float* d, int B, int Cin, int Cout, int T, int K,
+                            float in_scale, float slope, float eps, void* stream);
 /* The same for a table of weight tensors (host array, copied into the kernel arguments) in one
  * launch: all views of a network go stale together when its optimizer steps (trainer.py:90,94). */
 typedef struct {

@@ -356,3 +356,23 @@ def test_real_data_side_on_device(dev):
     rs.model_depth, rs.alpha = 0, 0.5
     with pytest.raises(ValueError):
         rs(w)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T", [(8, 64, 64, 1024), (9, 48, 40, 1000), (34, 64, 64, 1920)])
+def test_conv_pixelnorm_fused(dev, B, Cin, Cout, T):
+    """The generator layer in one kernel: conv -> LeakyReLU -> PixelNorm over channels -> multiplier
+    (layers.py:196-213, utils.py:133-136), against float64; also the normaliser it hands to backward."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 3, generator=g)
+    b = torch.randn(Cout, generator=g)
+    drop = torch.rand(B, Cout, generator=g) + 0.5
+    out = ops.conv1d_pixelnorm_raw(x.to(dev), w.to(dev), b.to(dev), drop.to(dev), in_scale=0.21, slope=0.2)
+    assert out is not None
+    y, d = out
+    h = F.leaky_relu(F.conv1d(x.double() * 0.21, w.double(), b.double(), padding=1), 0.2)
+    dref = torch.rsqrt((h * h).mean(dim=1) + 1e-8)
+    assert rel(d, dref) < TOL
+    assert rel(y, h * dref[:, None, :] * drop.double()[:, :, None]) < TOL
+    assert ops.conv1d_pixelnorm_raw(x[:2].to(dev), w.to(dev), None, None, in_scale=1.0, slope=0.2) is None  # too few subtiles
