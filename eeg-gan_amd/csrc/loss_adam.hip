@@ -108,7 +108,31 @@ __global__ __launch_bounds__(256) void adam_kernel(Pack pk, float lr, float b1, 
     const float lr_c = lr / bc1;
     int64_t end = start + CHUNK;
     if (end > t.n) end = t.n;
-    for (int64_t i = start + threadIdx.x; i < end; i += 256) {
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
+                       reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
+    int64_t i0 = start;
+    if (vec) {  // 16-byte accesses over the whole-float4 part of the chunk (start is a multiple of 4)
+        const int64_t nv = (end - start) / 4;
+        for (int64_t k = threadIdx.x; k < nv; k += 256) {
+            const int64_t i = start + 4 * k;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(t.g + i);
+            f32x4 m4 = *reinterpret_cast<const f32x4*>(t.m + i);
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(t.v + i);
+            f32x4 p4 = *reinterpret_cast<const f32x4*>(t.p + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = g4[e] * grad_scale;
+                m4[e] = b1 * m4[e] + (1.f - b1) * g;
+                v4[e] = b2 * v4[e] + (1.f - b2) * g * g;
+                p4[e] -= lr_c * m4[e] / (sqrtf(v4[e]) * inv_sqrt_bc2 + eps);
+            }
+            *reinterpret_cast<f32x4*>(t.m + i) = m4;
+            *reinterpret_cast<f32x4*>(t.v + i) = v4;
+            *reinterpret_cast<f32x4*>(t.p + i) = p4;
+        }
+        i0 = start + 4 * nv;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < end; i += 256) {
         const float g = t.g[i] * grad_scale;
         const float m = b1 * t.m[i] + (1.f - b1) * g;
         const float v = b2 * t.v[i] + (1.f - b2) * g * g;
