@@ -76,10 +76,14 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
 
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
                        iwass_drift_epsilon: float, grad_lambda: float, iwass_target: float,
-                       mixing: Optional[torch.Tensor] = None, stack_real_fake: Optional[bool] = None):
+                       mixing: Optional[torch.Tensor] = None, stack_real_fake: Optional[bool] = None,
+                       fake: Optional[torch.Tensor] = None):
     """WGAN-GP critic loss.  ``mixing`` optionally supplies the per-sample interpolation factors
     [B, 1, 1] (otherwise drawn like the reference does); used by parity tests.  ``stack_real_fake``:
-    evaluate reals and fakes in one stacked critic pass (default: when GDrop noise is drawn on the device)."""
+    evaluate reals and fakes in one stacked critic pass (default: when GDrop noise is drawn on the device).
+    ``fake``: fakes generated beforehand from ``z`` with the current generator (a trainer may generate
+    the fakes of all critic iterations of a step in one pass: the generator does not change between
+    them, reference trainer.py:83-91); ``gen`` is then not called."""
     if loss_type != "wgan_gp":
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
@@ -95,19 +99,25 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         # one after the other (losses.py:76-79); the result differs only in which GDrop draw a
         # sample meets, so the stacked pass is used when the noise comes from the device generator
         # and the sequential order when it follows the reference's host RNG stream.
-        with torch.no_grad():
-            g_, _ = gen(z)
-        fake_x = g_["x"]
+        if fake is None:
+            with torch.no_grad():
+                g_, _ = gen(z)
+            fake_x = g_["x"]
+        else:
+            fake_x = fake
         n = real_x.size(0)
         with layers.batch_segments(2):
             scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
         d_real, d_fake = scores[:n], scores[n:]
     else:
         d_real, _, _ = dis(real)
-        with torch.no_grad():
-            g_, _ = gen(z)
-        d_fake, _, _ = dis(g_)
-        fake_x = g_["x"]
+        if fake is None:
+            with torch.no_grad():
+                g_, _ = gen(z)
+            fake_x = g_["x"]
+        else:
+            fake_x = fake
+        d_fake, _, _ = dis({"x": fake_x})
     alpha = get_mixing_factor(real_x.size(0)) if mixing is None else mixing
     x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
     pred_hat, _, _ = dis(x_hat)
