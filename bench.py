@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--alpha", type=float, default=ALPHA, help="fade-in factor (< 1: mid-transition step)")
+    ap.add_argument("--per-iteration-fakes", action="store_true",
+                    help="one generator pass per critic iteration instead of one per step (comparison runs)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="reals start in pinned host memory and cross PCIe inside the timed region "
                          "(a side measurement; the headline value keeps them resident in HBM)")
@@ -174,6 +176,8 @@ def main():
     from eeggan_amd import layers
     layers.set_drop_mode(args.drop_mode)
     tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs)
+    if args.per_iteration_fakes:
+        tr.batch_fakes = False
 
     def barrier():
         if dist is not None:

@@ -94,6 +94,9 @@ class GraphedTrainer(Trainer):
     graphs -- forward + backward + gradient-bucket pack, and the Adam step reading the bucket --
     with the gradient all-reduce issued eagerly between the two replays."""
 
+    # generate the fakes of all critic iterations of a step in one generator pass
+    batch_fakes = True
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._key = None
@@ -122,7 +125,7 @@ class GraphedTrainer(Trainer):
         # ready-made fakes (losses.discriminator_loss does).
         d_loss_fn = self.d_loss
         self._fakes_call = self._zall = self._fake = None
-        if self.d_training_repeats > 1 and _accepts(self.d_loss, "fake"):
+        if self.batch_fakes and self.d_training_repeats > 1 and _accepts(self.d_loss, "fake"):
             self._zall = z.repeat(self.d_training_repeats, *([1] * (z.dim() - 1)))
 
             def all_fakes():
