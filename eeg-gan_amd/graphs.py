@@ -11,7 +11,7 @@ hipGraph and replayed with fresh inputs copied into static buffers.
 from __future__ import annotations
 
 import inspect
-from typing import Callable, Dict, Optional
+from typing import Callable, Optional
 
 import torch
 

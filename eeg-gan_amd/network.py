@@ -9,7 +9,6 @@ the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 from __future__ import annotations
 
 import numpy as np
-import torch
 from torch import nn
 
 from . import ops

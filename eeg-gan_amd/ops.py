@@ -15,9 +15,8 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
-import os
 import weakref
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 import torch

@@ -9,7 +9,7 @@ except that MinibatchStddev groups samples in fours with stride B/4 (reference l
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import torch
 import torch.distributed as dist

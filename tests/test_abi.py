@@ -1,6 +1,5 @@
 """The C-ABI library loads and exports every symbol that include/eeggan_hip.h declares
 (no compute call is made: this runs without a GPU)."""
-import ctypes
 import os
 import re
 

@@ -5,7 +5,6 @@ package's."""
 import os
 import socket
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -3,7 +3,6 @@ the same fp32 inputs) and against the per-op golden vectors produced by the refe
 
 Tolerance: 1e-4 relative in fp32 is the contract of the path; single kernels are held to 2e-5
 (norm-wise) because their fp32 rounding noise is ~1e-6."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
