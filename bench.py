@@ -114,7 +114,7 @@ def conv_roofline(dev, batch, T):
     sec = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * batch * C * C * K * T
     achieved = flops / sec / 1e12
-    # HBM bytes per launch from the PMC passes kept in profiles/r01_pmc_conv_ws_64x64_T1920_B32.csv
+    # HBM bytes per launch from the PMC passes kept in profiles/*pmc_conv_ws_64x64_T1920_B32.csv
     # (2 x FETCH_SIZE + WRITE_SIZE = 2 x 11588.4 KiB + 15360 KiB; the algorithmic figure is 31.5 MB:
     # input + output once, weights, multipliers).  Only valid for the profiled shape.
     traffic = (2 * 11588.4375 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
