@@ -1,0 +1,101 @@
+"""Per-kernel roofline table: each kernel family of the training step timed stand-alone with HIP events
+on the launch stream, at the per-GPU batch given on the command line, against the bound that limits it
+(fp32 MFMA 157.3 TFLOP/s for the contractions, HBM 8 TB/s for the rest).  Work per launch is the
+algorithmic figure: 2*B*Cout*Cin*K*T flop, or the bytes of the logical tensors read once and written once.
+
+usage: python scripts/kernel_roofline.py [B ...]      (default: 32 512)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eeggan_amd import ops, utils  # noqa: E402
+
+MFMA_PEAK = 157.3e12
+HBM_PEAK = 8.0e12
+dev = torch.device("cuda", 0)
+
+
+def timeit(fn, n):
+    """Average duration of one call: n calls captured into one HIP graph (so that the host's per-call cost
+    does not leave the GPU idle between them), the replay bracketed by events on the replay stream."""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(n):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def row(name, t, flop=None, nbytes=None):
+    if flop is not None:
+        print(f"{name:46s} {t * 1e6:9.1f} us  {flop / t / 1e12:7.1f} TFLOP/s  {flop / t / MFMA_PEAK:5.2f} of MFMA peak", flush=True)
+    else:
+        print(f"{name:46s} {t * 1e6:9.1f} us  {nbytes / t / 1e9:7.0f} GB/s     {nbytes / t / HBM_PEAK:5.2f} of HBM peak", flush=True)
+
+
+def run(B):
+    n = 30 if B <= 64 else 8
+    print(f"--- per-GPU batch {B} ---", flush=True)
+    convs = [(64, 64, 1920, 3), (64, 64, 1024, 3), (128, 128, 256, 3), (256, 256, 128, 3)]
+    for cin, cout, T, K in convs:
+        x = torch.randn(B, cin, T, device=dev)
+        w = torch.randn(cout, cin, K, device=dev)
+        b = torch.randn(cout, device=dev)
+        r = torch.rand(B, cout, device=dev) + 0.5
+        gy = torch.randn(B, cout, T, device=dev)
+        fl = 2.0 * B * cin * cout * K * T
+        tag = f"{cin}->{cout} k={K} T={T}"
+        row(f"conv fwd+lrelu+gdrop {tag}", timeit(lambda: ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2), n), flop=fl)
+        row(f"conv dgrad           {tag}", timeit(lambda: ops.conv1d_raw(gy, w, None, None, in_scale=0.1, transposed=True), n), flop=fl)
+        row(f"conv wgrad+reduce    {tag}", timeit(lambda: ops.conv1d_wgrad_raw(x, gy, K, in_scale=0.1), n), flop=fl)
+        if cin == 64 and ops.conv1d_pixelnorm_raw(x, w, b, r, in_scale=0.1, slope=0.2) is not None:
+            row(f"conv fwd+lrelu+pixelnorm+gdrop {tag}",
+                timeit(lambda: ops.conv1d_pixelnorm_raw(x, w, b, r, in_scale=0.1, slope=0.2), n), flop=fl)
+        del x, w, b, r, gy
+    # 1x1 convs on five channels: bandwidth-bound
+    for cin, cout in ((64, 5), (5, 64)):
+        T = 1920
+        x = torch.randn(B, cin, T, device=dev)
+        w = torch.randn(cout, cin, 1, device=dev)
+        b = torch.randn(cout, device=dev)
+        row(f"conv 1x1 {cin}->{cout} T={T}", timeit(lambda: ops.conv1d_raw(x, w, b, None, in_scale=0.1, act=1, act_param=0.2), n),
+            nbytes=4.0 * B * T * (cin + cout))
+        del x
+    C, T = 64, 1920
+    h = torch.randn(B, C, T, device=dev)
+    g = torch.randn(B, C, T, device=dev)
+    r = torch.rand(B, C, device=dev) + 0.5
+    y, d = ops.pixelnorm_drop_fwd_raw(h, r)
+    row("pixelnorm+gdrop fwd [B,64,1920]", timeit(lambda: ops.pixelnorm_drop_fwd_raw(h, r), n), nbytes=2.0 * 4 * B * C * T)
+    row("pixelnorm+gdrop+lrelu bwd [B,64,1920]", timeit(lambda: ops.pixelnorm_drop_bwd_raw(g, y, r, d, 0.2), n), nbytes=3.0 * 4 * B * C * T)
+    row("lrelu+gdrop bwd [B,64,1920]", timeit(lambda: ops.lrelu_drop_bwd_raw(g, h, r, 0.2), n), nbytes=3.0 * 4 * B * C * T)
+    row("axpby (blend) [B,64,1920]", timeit(lambda: ops.axpby_raw(h, 0.3, g, 0.7), n), nbytes=3.0 * 4 * B * C * T)
+    with torch.no_grad():
+        hc = h[:, :, :1280].contiguous()
+        row("resample 1280->1920 (x3/2) [B,64,.]", timeit(lambda: utils.resample_signal(hc, 1280, 1920), n),
+            nbytes=4.0 * B * C * (1280 + 1920))
+        row("resample 1920->1280 (x2/3) [B,64,.]", timeit(lambda: utils.resample_signal(h, 1920, 1280), n),
+            nbytes=4.0 * B * C * (1280 + 1920))
+        xm = torch.randn(B, 256, 32, device=dev)
+        row("minibatch stddev fwd [B,256,32]", timeit(lambda: ops.minibatch_stddev(xm, 4), n), nbytes=4.0 * B * 32 * (256 + 257))
+    real = torch.randn(B, 5, T, device=dev)
+    fake = torch.randn(B, 5, T, device=dev)
+    mix = torch.rand(B, device=dev)
+    row("x_hat mix [B,5,1920]", timeit(lambda: ops.mix_batch_raw(real, fake, mix), n), nbytes=3.0 * 4 * B * 5 * T)
+
+
+if __name__ == "__main__":
+    for B in ([int(a) for a in sys.argv[1:]] or [32, 512]):
+        run(B)
