@@ -266,7 +266,22 @@ __global__ __launch_bounds__(256) void tail_dgrad_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (k < Kd) {
-        for (int co = cg; co < Cout; co += 4) {
+        // eight weight rows in flight per thread: the loop is bound by the latency of these loads
+        int co = cg;
+        for (; co + 28 < Cout; co += 32) {
+            f32x4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = *reinterpret_cast<const f32x4*>(w + (long long)(co + 4 * u) * Kd + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = gsh[j * Cout + co + 4 * u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] += g * wv[u][e];
+                }
+        }
+        for (; co < Cout; co += 4) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long long)co * Kd + k);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -314,7 +329,21 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
         f32x4 acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int b = 0; b < B; ++b) {
+        int b = 0;
+        for (; b + 8 <= B; b += 8) {  // eight sample rows in flight per thread (latency-bound loop)
+            f32x4 xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + (long long)(b + u) * Kd + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float g = gsh[(b + u) * 8 + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c][e] += g * xv[u][e];
+                }
+        }
+        for (; b < B; ++b) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)b * Kd + k);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
