@@ -38,6 +38,7 @@ SIGNATURES = {
     "eeggan_conv1d_wgrad_partial": (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _fl, _f, _sz, C.c_void_p, C.c_void_p,
                                          _st]),
     "eeggan_wgrad_reduce_multi": (_i, [C.c_void_p, _i, _st]),
+    "eeggan_conv1d_wgrad_partial_multi": (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _st]),
     "eeggan_head_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),
     "eeggan_head_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_head_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),

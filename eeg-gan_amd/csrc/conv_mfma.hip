@@ -732,7 +732,7 @@ struct WgradArgs {
 // channels or time, with one wave-uniform (sample, time) decode per iteration, two LDS buffers and a
 // single barrier per iteration.  Otherwise the generic XStage path.
 template <int K, bool FULL>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NTW = 2;
     constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
@@ -745,10 +745,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int h = lane >> 5;
     const int wave = tid >> 6;
     const int cot = wave >> 1, cit = wave & 1;
-    const int region = blockIdx.y;
     const int co0 = (region / a.nci) * 64;
     const int ci0 = (region % a.nci) * 64;
-    const int split = blockIdx.x;
     const bool do_bias = a.ws_b != nullptr && ci0 == 0 && cit == 0;
 
     f32x16 acc[K];
@@ -909,6 +907,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int co = co0 + cot * 32 + l31;
         if (h == 0 && co < a.Cout) a.ws_b[(long long)split * a.Cout + co] = bsum;
     }
+}
+
+template <int K, bool FULL>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    wgrad_body<K, FULL>(a, blockIdx.x, blockIdx.y);
+}
+
+// Several independent weight gradients in one launch: the workgroups of the grid are dealt out to the
+// jobs in proportion to their work, so that a group of layers shares ONE chip-wide round of
+// workgroups.  Each job then has fewer, longer splits: a fraction of the partial slabs to write and
+// to sum, and one launch latency for the group.
+constexpr int WG_MAXJ = 16;
+struct WgradPack {
+    WgradArgs j[WG_MAXJ];
+    int first[WG_MAXJ + 1];  // first workgroup of job k; first[n] = grid size
+    int n;
+};
+
+template <int K, bool FULL>
+__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradPack pk) {
+    const int blk = blockIdx.x;
+    int k = 0;
+    while (k + 1 < pk.n && blk >= pk.first[k + 1]) ++k;
+    const WgradArgs a = pk.j[k];
+    const int local = blk - pk.first[k];
+    const int region = local / a.nsplit;
+    wgrad_body<K, FULL>(a, local - region * a.nsplit, region);
 }
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
@@ -1208,6 +1233,107 @@ extern "C" int eeggan_conv1d_wgrad_partial(const float* x, const float* gy, int 
         job_b->nsplit = p.nsplit;
         job_b->scale = 1.f;
         job_b->beta = 0.f;
+    }
+    return 0;
+}
+
+extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, int njobs, eeggan_reduce_job* jobs_w,
+                                                 eeggan_reduce_job* jobs_b, void* stream) {
+    EEGGAN_REQUIRE(jobs && jobs_w && jobs_b && njobs > 0, "conv1d_wgrad_partial_multi: bad table");
+    hipStream_t st = as_stream(stream);
+    constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
+    const int cus = num_cus();
+    // kernel variant per job: 0 = K 3 without predicates, 1 = K 3 generic, 2 = K 1
+    auto variant = [](const eeggan_wgrad_job& j) {
+        const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
+        return j.K == 3 ? (full ? 0 : 1) : 2;
+    };
+    for (int i = 0; i < njobs; ++i) {
+        const eeggan_wgrad_job& j = jobs[i];
+        if (check_common(j.B, j.Cin, j.Cout, j.T, j.K)) return 1;
+        EEGGAN_REQUIRE(j.x && j.gy, "conv1d_wgrad_partial_multi: job %d: null x/gy pointer", i);
+        const WgradPlan p = plan_wgrad(j.B, j.Cin, j.Cout, j.T, j.K);
+        EEGGAN_REQUIRE(j.workspace && j.workspace_bytes >= p.bytes,
+                       "conv1d_wgrad_partial_multi: job %d: workspace too small (%zu < %zu bytes)", i,
+                       j.workspace_bytes, p.bytes);
+    }
+    for (int v = 0; v < 3; ++v) {
+        int idx[WG_MAXJ];
+        int n = 0;
+        auto flush = [&]() -> int {
+            if (n == 0) return 0;
+            WgradPlan plan[WG_MAXJ];
+            long long pairs[WG_MAXJ], units = 0, longest = 1;
+            for (int k = 0; k < n; ++k) {
+                const eeggan_wgrad_job& j = jobs[idx[k]];
+                plan[k] = plan_wgrad(j.B, j.Cin, j.Cout, j.T, j.K);
+                pairs[k] = ((long long)j.B * ((j.T + 31) / 32) + 1) / 2;
+                units += pairs[k] * plan[k].regions;
+                if (pairs[k] > longest) longest = pairs[k];
+            }
+            // the smallest common split length that keeps the whole group within one workgroup per CU
+            // (never shorter than a job's own plan: its workspace is sized for that many slabs)
+            long long iters = (units + cus - 1) / cus;
+            if (iters < 1) iters = 1;
+            for (;; ++iters) {
+                long long wgs = 0;
+                for (int k = 0; k < n; ++k) {
+                    const long long it = iters > plan[k].iters ? iters : plan[k].iters;
+                    wgs += ((pairs[k] + it - 1) / it) * plan[k].regions;
+                }
+                if (wgs <= cus || n == 1 || iters >= longest) break;
+            }
+            WgradPack pk;
+            pk.n = n;
+            int first = 0;
+            for (int k = 0; k < n; ++k) {
+                const eeggan_wgrad_job& j = jobs[idx[k]];
+                const long long it = iters > plan[k].iters ? iters : plan[k].iters;
+                const int nsplit = (int)((pairs[k] + it - 1) / it);
+                WgradArgs& a = pk.j[k];
+                a.x = j.x; a.gy = j.gy; a.mask_y = j.mask_y; a.mask_drop = j.mask_y ? j.mask_drop : nullptr;
+                a.mask_slope = j.mask_slope;
+                a.ws = static_cast<float*>(j.workspace);
+                a.ws_b = j.want_bias ? a.ws + (size_t)nsplit * plan[k].slab_elems : nullptr;
+                a.B = j.B; a.Cin = j.Cin; a.Cout = j.Cout; a.T = j.T;
+                a.ST = (j.T + 31) / 32;
+                a.NS = j.B * a.ST;
+                a.nci = plan[k].nci; a.nsplit = nsplit; a.iters = (int)it;
+                a.vec = (j.T % 4 == 0) ? 1 : 0;
+                pk.first[k] = first;
+                first += nsplit * plan[k].regions;
+                eeggan_reduce_job& rw = jobs_w[idx[k]];
+                rw.slabs = a.ws; rw.out = nullptr; rw.elems = (int64_t)plan[k].slab_elems; rw.nsplit = nsplit;
+                rw.scale = j.in_scale; rw.beta = 0.f; rw.reserved = 0;
+                eeggan_reduce_job& rb = jobs_b[idx[k]];
+                rb.slabs = a.ws_b; rb.out = nullptr; rb.elems = j.want_bias ? j.Cout : 0; rb.nsplit = nsplit;
+                rb.scale = 1.f; rb.beta = 0.f; rb.reserved = 0;
+            }
+            for (int k = n; k <= WG_MAXJ; ++k) pk.first[k] = first;
+            if (v == 0) {
+                static bool ready = false;  // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once)
+                if (!ready) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                    EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad_partial_multi: cannot reserve LDS: %s",
+                                   hipGetErrorString(e));
+                    ready = true;
+                }
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
+            } else if (v == 1) {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, false>), dim3(first), dim3(256), lds1, st, pk);
+            } else {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<1, false>), dim3(first), dim3(256), lds1, st, pk);
+            }
+            n = 0;
+            return check_launch("conv1d_wgrad_partial_multi");
+        };
+        for (int i = 0; i < njobs; ++i) {
+            if (variant(jobs[i]) != v) continue;
+            idx[n++] = i;
+            if (n == WG_MAXJ && flush()) return 1;
+        }
+        if (flush()) return 1;
     }
     return 0;
 }

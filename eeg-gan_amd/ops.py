@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 import weakref
 from typing import Optional
 
@@ -214,6 +215,20 @@ class _ReduceJob(ctypes.Structure):
                 ("reserved", ctypes.c_int)]
 
 
+class _WgradJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("gy", ctypes.c_void_p), ("mask_y", ctypes.c_void_p),
+                ("mask_drop", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("B", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("T", ctypes.c_int),
+                ("K", ctypes.c_int), ("want_bias", ctypes.c_int), ("in_scale", ctypes.c_float),
+                ("mask_slope", ctypes.c_float)]
+
+
+# Weight gradients of a backward pass are submitted in groups of this many layers per launch (the
+# library deals the chip's workgroups out to the jobs of a group): each layer is then cut into fewer
+# splits, so there are fewer partial slabs to write and sum, and a group pays one launch latency.
+WGRAD_GROUP = int(os.environ.get("EEGGAN_WGRAD_GROUP", "16"))
+
+
 class _DirectGrads:
     def __init__(self):
         self.enabled = False
@@ -221,6 +236,7 @@ class _DirectGrads:
         self.keep = []      # workspaces the pending reductions still read
         self.jobs = []      # (round, job): jobs of one round write distinct buffers
         self.touched = {}   # id(param) -> [param, contributions so far in this backward pass]
+        self.pending = {}   # kernel variant -> [(job, tensors it reads, parameters)] not yet submitted
         self.queued = False
 
     def usable(self, w):
@@ -253,25 +269,51 @@ class _DirectGrads:
         Cout, K = gy.shape[1], w.shape[2]
         if gy.shape[0] != B or gy.shape[2] != T or tuple(w.shape) != (Cout, Cin, K):
             raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)}, gy {tuple(gy.shape)}, w {tuple(w.shape)} disagree")
+        for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
+            if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
+                raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
         nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-        jw, jb = _ReduceJob(), _ReduceJob()
-        call("eeggan_conv1d_wgrad_partial", x.data_ptr(), gy.data_ptr(), int(bias is not None), B, Cin, Cout, T, K,
-             float(in_scale), _p(mask_y), _p(mask_drop), float(slope), ws.data_ptr(), nbytes, ctypes.byref(jw),
-             ctypes.byref(jb), _stream())
-        for p, job in ((w, jw), (bias, jb)):
-            if p is not None:
-                buf, beta, rnd = self._slot(p)
-                job.out, job.beta = buf.data_ptr(), beta
-                self.jobs.append((rnd, job))
-        self.keep.append(ws)
+        job = _WgradJob(x.data_ptr(), gy.data_ptr(), _p(mask_y), _p(mask_drop), ws.data_ptr(), nbytes, B, Cin, Cout,
+                        T, K, int(bias is not None), float(in_scale), float(slope))
+        # the tensors stay referenced until the group is submitted: nothing may recycle their memory
+        # (jobs that run the same kernel variant share a launch, so they are queued per variant)
+        variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0)
+        queue = self.pending.setdefault(variant, [])
+        queue.append((job, (x, gy, mask_y, mask_drop, ws), (w, bias)))
         self.stream = _stream()
         if not self.queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self.queued = True
+        if len(queue) >= WGRAD_GROUP:
+            self.submit(variant)
+
+    def submit(self, variant=None):
+        """Launch the queued weight-gradient jobs (of one kernel variant, or all) and register their slab
+        reductions."""
+        if variant is None:
+            for v in list(self.pending):
+                self.submit(v)
+            return
+        pending = self.pending.pop(variant, [])
+        if not pending:
+            return
+        n = len(pending)
+        table = (_WgradJob * n)(*[p[0] for p in pending])
+        jw, jb = (_ReduceJob * n)(), (_ReduceJob * n)()
+        call("eeggan_conv1d_wgrad_partial_multi", table, n, jw, jb, self.stream)
+        for i, (_, tensors, (w, bias)) in enumerate(pending):
+            for p, src in ((w, jw[i]), (bias, jb[i])):
+                if p is not None:
+                    job = _ReduceJob(src.slabs, None, src.elems, src.nsplit, src.scale, 0.0, 0)
+                    buf, beta, rnd = self._slot(p)
+                    job.out, job.beta = buf.data_ptr(), beta
+                    self.jobs.append((rnd, job))
+            self.keep.append(tensors[4])
 
     def finish(self):
         try:
+            self.submit()
             for rnd in sorted({r for r, _ in self.jobs}):
                 jobs = [j for r, j in self.jobs if r == rnd]
                 table = (_ReduceJob * len(jobs))(*jobs)
@@ -279,7 +321,7 @@ class _DirectGrads:
             for p, _ in self.touched.values():
                 p.grad = p._eeggan_grad
         finally:
-            self.touched, self.keep, self.jobs, self.queued = {}, [], [], False
+            self.touched, self.keep, self.jobs, self.pending, self.queued = {}, [], [], {}, False
 
 
 _direct = _DirectGrads()

@@ -102,6 +102,23 @@ int eeggan_conv1d_wgrad_partial(const float* x, const float* gy, int want_bias,
                                 void* workspace, size_t workspace_bytes,
                                 eeggan_reduce_job* job_w, eeggan_reduce_job* job_b, void* stream);
 int eeggan_wgrad_reduce_multi(const eeggan_reduce_job* jobs, int njobs, void* stream);
+/* eeggan_conv1d_wgrad_partial for a group of independent layers in as few launches as their kernel
+ * variants allow (one for layers with channels % 64 == 0, T % 32 == 0, K = 3): the chip's workgroups
+ * are dealt out to the jobs in proportion to their work, so each job is cut into fewer splits than on
+ * its own -- fewer slabs to write and to sum, one launch latency per group.  Arguments per job as in
+ * eeggan_conv1d_wgrad_partial (workspace sized by eeggan_conv1d_wgrad_workspace); jobs_w[i] / jobs_b[i]
+ * receive job i's reduce descriptors (jobs_b[i].elems = 0 without want_bias).  x, gy and the masks of
+ * every job must stay untouched until the call; a backward pass therefore queues its weight gradients
+ * and submits them in groups (the reference computes them one by one inside autograd,
+ * layers.py:173-174 under loss.backward(), trainer.py:89). */
+typedef struct {
+    const float* x; const float* gy; const float* mask_y; const float* mask_drop;
+    void* workspace; size_t workspace_bytes;
+    int B, Cin, Cout, T, K, want_bias;
+    float in_scale, mask_slope;
+} eeggan_wgrad_job;
+int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, int njobs,
+                                      eeggan_reduce_job* jobs_w, eeggan_reduce_job* jobs_b, void* stream);
 
 /* ---- G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal (network.py:158-159,302-303) --
  *   y[b,co,t] = drop[b,co]*act(bias[co] + in_scale * sum_ci w[co,ci,KT-1-t] * z[b,ci]),  t in [0,KT)
