@@ -327,6 +327,44 @@ class _DirectGrads:
 _direct = _DirectGrads()
 
 
+def conv1d_wgrad_group_raw(jobs):
+    """Weight/bias gradients of several independent layers through the grouped entry points.
+    ``jobs``: dicts with x, gy, K and optionally in_scale, need_bias, mask_y, mask_drop, mask_slope (as
+    ``conv1d_wgrad_raw``); returns a list of (gw, gb)."""
+    n = len(jobs)
+    table, keep, outs = (_WgradJob * n)(), [], []
+    for i, j in enumerate(jobs):
+        x, gy, K = _chk(j["x"], "wgrad x"), _chk(j["gy"], "wgrad gy"), int(j["K"])
+        B, Cin, T = x.shape
+        Cout = gy.shape[1]
+        if gy.shape[0] != B or gy.shape[2] != T:
+            raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)} and gy {tuple(gy.shape)} disagree")
+        mask_y, mask_drop = j.get("mask_y"), j.get("mask_drop")
+        for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
+            if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
+                raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
+        nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        need_bias = bool(j.get("need_bias", True))
+        table[i] = _WgradJob(x.data_ptr(), gy.data_ptr(), _p(mask_y), _p(mask_drop), ws.data_ptr(), nbytes, B, Cin,
+                             Cout, T, K, int(need_bias), float(j.get("in_scale", 1.0)), float(j.get("mask_slope", 0.0)))
+        keep.append((x, gy, mask_y, mask_drop, ws))
+        gw = torch.empty((Cout, Cin, K), device=x.device, dtype=torch.float32)
+        gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
+        outs.append((gw, gb))
+    jw, jb = (_ReduceJob * n)(), (_ReduceJob * n)()
+    call("eeggan_conv1d_wgrad_partial_multi", table, n, jw, jb, _stream())
+    red = []
+    for i, (gw, gb) in enumerate(outs):
+        jw[i].out = gw.data_ptr()
+        red.append(jw[i])
+        if gb is not None:
+            jb[i].out = gb.data_ptr()
+            red.append(jb[i])
+    call("eeggan_wgrad_reduce_multi", (_ReduceJob * len(red))(*red), len(red), _stream())
+    return outs
+
+
 @contextlib.contextmanager
 def direct_weight_grads(enabled=True):
     prev, _direct.enabled = _direct.enabled, bool(enabled)
