@@ -13,6 +13,7 @@ Prints ONE JSON line (rank 0).  ``value`` counts local-batch training steps per 
 over all ranks (weak scaling: the global batch is 32 x N).
 """
 import argparse
+import functools
 import json
 import os
 import sys
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--alpha", type=float, default=ALPHA, help="fade-in factor (< 1: mid-transition step)")
+    ap.add_argument("--lockstep-penalty", action="store_true",
+                    help="run the critic pass over the penalty's interpolates in lockstep with the stacked "
+                         "reals+fakes pass instead of on its own (comparison; slower, see losses.discriminator_loss)")
     ap.add_argument("--per-iteration-fakes", action="store_true",
                     help="one generator pass per critic iteration instead of one per step (comparison runs)")
     ap.add_argument("--host-inputs", action="store_true",
@@ -178,6 +182,8 @@ def main():
     tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs)
     if args.per_iteration_fakes:
         tr.batch_fakes = False
+    if args.lockstep_penalty:
+        tr.d_loss = functools.partial(tr.d_loss, lockstep_penalty=True)
 
     def barrier():
         if dist is not None:

@@ -132,7 +132,7 @@ def flipped_weights(w, cache=None):
 
 
 def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, act=ACT_NONE, act_param=0.0,
-               act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0, flip=None):
+               act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0, flip=None, out=None):
     x = _chk(x, "conv1d x")
     w = _chk(w, "conv1d w")
     B, Cin, T = x.shape
@@ -150,7 +150,12 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
                               or not t.is_cuda):
             raise RuntimeError(f"conv1d: {name} must be a contiguous float32 device tensor of shape {shape}, "
                                f"got {tuple(t.shape)}")
-    y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    if out is None:
+        y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    else:
+        y = out
+        if tuple(y.shape) != (B, Cout, T) or not y.is_contiguous() or y.dtype != torch.float32 or y.device != x.device:
+            raise RuntimeError(f"conv1d: out must be a contiguous float32 tensor of shape {(B, Cout, T)}")
     call("eeggan_conv1d", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, T, K,
          float(in_scale), int(act), float(act_param), _p(act_aux), _p(mask_y), _p(mask_drop), float(mask_slope),
          _stream())
@@ -413,13 +418,16 @@ def axpby_raw(a, ca, b=None, cb=0.0):
     return out
 
 
-def mix_batch_raw(real, fake, mix):
+def mix_batch_raw(real, fake, mix, out=None):
     real = _chk(real, "mix real")
     fake = _chk(fake, "mix fake")
     mix = _chk(mix.reshape(-1), "mix factors")
     if real.shape != fake.shape or mix.numel() != real.shape[0]:
         raise RuntimeError("mix_batch: shape mismatch")
-    out = torch.empty_like(real)
+    if out is None:
+        out = torch.empty_like(real)
+    elif out.shape != real.shape or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError("mix_batch: out does not match the inputs")
     call("eeggan_mix_batch", real.data_ptr(), fake.data_ptr(), mix.data_ptr(), out.data_ptr(), real.shape[0],
          real[0].numel(), _stream())
     return out
@@ -501,6 +509,10 @@ class _Conv(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, drop, y, bias = ctx.saved_tensors
+        # The layer output only selects the LeakyReLU branch below (zero derivative): detached, so that a
+        # twice-differentiated pass does not tie its backward graph to this node's own backward -- the
+        # engine would otherwise run it once more on gradients that are identically zero.
+        y = None if y is None else y.detach()
         gy = _chk(gy, "conv grad")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -516,6 +528,177 @@ class _Conv(Function):
 def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None):
     """Fused equalized conv layer of the discriminator path (twice differentiable)."""
     return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip)
+
+
+# --------------------------------------------------------------------------------------- lockstep passes
+# Several independent minibatches can go through the critic in lockstep ("parts": e.g. the stacked
+# reals+fakes and the gradient-penalty interpolates, which need autograd graphs of their own because
+# only the latter is differentiated twice).  While the parts of an activation lie back to back in ONE
+# allocation, a layer runs ONE launch over all of them and hands out views; each part still has its
+# own place in the autograd graph: a backward call that gets the gradient of only one part (the
+# penalty's first-order pass) works on that part alone, the end-of-iteration backward, which gets all
+# of them, again runs one launch over the union.
+class Parts:
+    """Minibatches in lockstep: ``t`` the tensors, ``segments`` how many independent minibatches each
+    one stacks (MinibatchStddev statistics stay inside a minibatch)."""
+
+    def __init__(self, tensors, segments=None):
+        self.t = list(tensors)
+        self.segments = list(segments) if segments is not None else [1] * len(self.t)
+
+    def like(self, tensors):
+        return Parts(tensors, self.segments)
+
+    @property
+    def shape(self):  # of the first part: the parts agree in everything but the batch
+        return self.t[0].shape
+
+    @property
+    def device(self):
+        return self.t[0].device
+
+
+def _union(ts):
+    """One tensor over the memory of ``ts`` if they lie back to back in one allocation (contiguous
+    float32, equal trailing shapes), else None."""
+    if any(t is None for t in ts):
+        return None
+    t0 = ts[0]
+    if len(ts) == 1:
+        return t0 if t0.is_contiguous() else None
+    base = t0.untyped_storage().data_ptr()
+    off, rows = t0.storage_offset(), 0
+    for t in ts:
+        if (not t.is_contiguous() or t.dtype != torch.float32 or t.shape[1:] != t0.shape[1:]
+                or t.untyped_storage().data_ptr() != base or t.storage_offset() != off):
+            return None
+        off += t.numel()
+        rows += t.shape[0]
+    return t0.detach().as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
+
+
+def _split(t, like):
+    return list(torch.split(t, [p.shape[0] for p in like]))
+
+
+class _ConvParts(Function):
+    """``_Conv`` for parts in lockstep (same weights, one launch while the parts are adjacent in memory)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, in_scale, act, slope, flip, n, *xd):
+        if act not in (ACT_NONE, ACT_LRELU):
+            raise ValueError("_ConvParts supports linear and leaky-relu epilogues")
+        xs, drops = [_chk(x, "conv x") for x in xd[:n]], list(xd[n:])
+        has_drop = drops[0] is not None
+        if act == ACT_NONE and has_drop:
+            raise ValueError("a drop multiplier needs the leaky-relu epilogue")
+        xu = _union(xs)
+        du = _union(drops) if has_drop else None
+        if xu is not None and (du is not None or not has_drop):
+            ys = _split(conv1d_raw(xu, w, bias, du, in_scale=in_scale, act=act, act_param=slope), xs)
+        else:
+            ys = [conv1d_raw(x, w, bias, d, in_scale=in_scale, act=act, act_param=slope) for x, d in zip(xs, drops)]
+        ctx.n, ctx.flip, ctx.in_scale, ctx.slope, ctx.has_bias = n, flip, in_scale, slope, bias is not None
+        ctx.masked = act == ACT_LRELU
+        ctx.save_for_backward(w, bias, *xs, *drops, *(ys if ctx.masked else []))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        w, bias = saved[0], saved[1]
+        xs, drops = list(saved[2:2 + n]), list(saved[2 + n:2 + 2 * n])
+        ys = [y.detach() for y in saved[2 + 2 * n:2 + 3 * n]] if ctx.masked else [None] * n  # (as in _Conv)
+        gys = [None if g is None else _chk(g, "conv grad") for g in gys]
+        live = [i for i in range(n) if gys[i] is not None]
+        need_x = [ctx.needs_input_grad[7 + i] for i in range(n)]
+        want_w = (ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1])) and not _input_grad_only
+        direct = _direct.usable(w) and (bias is None or _direct.usable(bias))
+        gxs, gw, gb = [None] * n, None, None
+        joint = (not torch.is_grad_enabled() and len(live) == n and n > 1 and (direct or not want_w)
+                 and all(need_x[i] == need_x[0] for i in range(n)))
+        xu = yu = du = None
+        if joint:  # the saved operands must be adjacent, the gradients are made so below
+            xu, du = _union(xs), (_union(drops) if drops[0] is not None else None)
+            yu = _union(ys) if ctx.masked else None
+            joint = (xu is not None and (du is not None or drops[0] is None) and (yu is not None or not ctx.masked))
+        if joint:
+            gyu = _union(gys)
+            if need_x[0]:
+                if gyu is not None:
+                    gxs = _split(conv1d_raw(gyu, w, None, None, in_scale=ctx.in_scale, transposed=True, mask_y=yu,
+                                            mask_drop=du, mask_slope=ctx.slope, flip=ctx.flip), xs)
+                else:  # gradients arrive apart: one launch per part, into one buffer, adjacent from here on
+                    gxs = _split(torch.empty_like(xu), xs)
+                    for i in range(n):
+                        conv1d_raw(gys[i], w, None, None, in_scale=ctx.in_scale, transposed=True, mask_y=ys[i],
+                                   mask_drop=drops[i], mask_slope=ctx.slope, flip=ctx.flip, out=gxs[i])
+            if want_w:
+                if gyu is not None:
+                    _direct.wgrad(w, bias, xu, gyu, ctx.in_scale, yu, du, ctx.slope)
+                else:
+                    for i in range(n):
+                        _direct.wgrad(w, bias, xs[i], gys[i], ctx.in_scale, ys[i], drops[i], ctx.slope)
+        else:
+            for i in live:
+                if need_x[i]:
+                    gxs[i] = _ConvT.apply(gys[i], w, ys[i], drops[i], ctx.in_scale, ctx.slope, ctx.flip)
+                if want_w:
+                    if direct:
+                        _direct.wgrad(w, bias, xs[i], gys[i], ctx.in_scale, ys[i], drops[i], ctx.slope)
+                    else:
+                        pw, pb = _WGrad.apply(xs[i], gys[i], w.shape[2], ctx.in_scale, ctx.has_bias, ys[i], drops[i],
+                                              ctx.slope)
+                        gw = pw if gw is None else gw + pw
+                        if pb is not None:
+                            gb = pb if gb is None else gb + pb
+        return (gw, gb, None, None, None, None, None, *gxs, *([None] * n))
+
+
+def conv1d_parts(xs, w, bias, drops, in_scale, act, slope=0.0, flip=None):
+    """``conv1d`` for parts in lockstep; returns the list of outputs."""
+    n = len(xs)
+    return list(_ConvParts.apply(w, bias, float(in_scale), int(act), float(slope), flip, n, *xs, *drops))
+
+
+class _GatherParts(Function):
+    """``_Gather`` (the resampler) for parts in lockstep."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, *xs):
+        xs = [_chk(x, "resample x") for x in xs]
+        ctx.tables = (fwd, bwd)
+        xu = _union(xs)
+        if xu is not None:
+            return tuple(_split(_gather_raw(xu, fwd), xs))
+        return tuple(_gather_raw(x, fwd) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        fwd, bwd = ctx.tables
+        n = len(gs)
+        need = [ctx.needs_input_grad[2 + i] for i in range(n)]
+        out = [None] * n
+        if not torch.is_grad_enabled() and n > 1 and all(g is not None for g in gs) and all(need):
+            gs = [_chk(g, "resample grad") for g in gs]
+            gu = _union(gs)
+            if gu is not None:
+                return (None, None, *_split(_gather_raw(gu, bwd), gs))
+            rows = sum(g.shape[0] for g in gs)
+            buf = torch.empty((rows,) + tuple(gs[0].shape[1:-1]) + (bwd[3],), device=gs[0].device, dtype=torch.float32)
+            out = _split(buf, gs)
+            for g, o in zip(gs, out):
+                _gather_raw(g, bwd, out=o)
+            return (None, None, *out)
+        for i, g in enumerate(gs):
+            if g is not None and need[i]:
+                out[i] = _Gather.apply(g, bwd, fwd)
+        return (None, None, *out)
+
+
+def gather_parts(xs, fwd, bwd):
+    return list(_GatherParts.apply(fwd, bwd, *xs))
 
 
 # --------------------------------------------------------------------------------------- D tail
@@ -610,7 +793,7 @@ class _Tail(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, drop, y = ctx.saved_tensors
-        gc = _MaskMul.apply(_chk(gy, "tail grad"), y, drop, ctx.slope)
+        gc = _MaskMul.apply(_chk(gy, "tail grad"), y.detach(), drop, ctx.slope)  # (as in _Conv)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _TailT.apply(gc, w, ctx.in_scale)
@@ -722,21 +905,28 @@ def pixel_norm(h):
 
 
 # --------------------------------------------------------------------------------------- linear helpers
+def _gather_raw(x, table, out=None):
+    x = _chk(x, "resample x")
+    idx, coef, t_in, t_out, taps = table
+    if x.shape[-1] != t_in:
+        raise RuntimeError(f"resample: input length {x.shape[-1]} does not match the table ({t_in})")
+    rows = x.numel() // t_in
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != tuple(x.shape[:-1]) + (t_out,) or not out.is_contiguous():
+        raise RuntimeError("resample: out does not match the result shape")
+    call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
+         taps, _stream())
+    return out
+
+
 class _Gather(Function):
     """out[r, m] = sum_k coef[m, k] * x[r, idx[m, k]]; the backward is the same op with the transposed table."""
 
     @staticmethod
     def forward(ctx, x, fwd, bwd):
-        x = _chk(x, "resample x")
-        idx, coef, t_in, t_out, taps = fwd
-        if x.shape[-1] != t_in:
-            raise RuntimeError(f"resample: input length {x.shape[-1]} does not match the table ({t_in})")
-        rows = x.numel() // t_in
-        out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
-        call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
-             taps, _stream())
         ctx.tables = (fwd, bwd)
-        return out
+        return _gather_raw(x, fwd)
 
     @staticmethod
     def backward(ctx, g):
