@@ -15,8 +15,6 @@
 //     channel) multiplier are applied on the way).
 #include "common.h"
 #include "conv_args.h"
-
-#include <cstdlib>
 #include <type_traits>
 
 namespace eeggan {
@@ -401,7 +399,11 @@ int launch(const ConvArgs& a, hipStream_t st) {
 template <int K, bool MASKED, bool FULL>
 int launch_rm(const ConvArgs& a, hipStream_t st) {
     // whole-subtile units once every SIMD has at least two of them to interleave, half units below
-    const bool halves = a.act != ACT_LRELU_PN && a.NS < 8 * num_cus();  // (the norm needs all channels in one unit)
+    // ... or when halves fill the chip's rounds of waves better (e.g. 2560 subtiles on 2048 waves: 2 rounds of
+    // whole units, 3 rounds of half units = 1.5)
+    const long long waves = 8ll * num_cus();
+    const long long whole = (a.NS + waves - 1) / waves * 2, half = (2ll * a.NS + waves - 1) / waves;
+    const bool halves = a.act != ACT_LRELU_PN && (a.NS < waves || half < whole);  // (the norm needs all channels in one unit)
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
 
