@@ -232,6 +232,10 @@ class _WgradJob(ctypes.Structure):
 # library deals the chip's workgroups out to the jobs of a group): each layer is then cut into fewer
 # splits, so there are fewer partial slabs to write and sum, and a group pays one launch latency.
 WGRAD_GROUP = int(os.environ.get("EEGGAN_WGRAD_GROUP", "16"))
+# ... unless the layer keeps the chip busy for many rounds by itself (work units = 64x64-channel regions x
+# pairs of 32-sample subtiles; 256 workgroups take one unit each per round): grouping then only delays
+# the launch and holds on to the layer's activations (measured at 512 samples per GPU: 4 % slower grouped).
+WGRAD_SOLO_UNITS = 8 * 256
 
 
 class _DirectGrads:
@@ -284,13 +288,16 @@ class _DirectGrads:
         # the tensors stay referenced until the group is submitted: nothing may recycle their memory
         # (jobs that run the same kernel variant share a launch, so they are queued per variant)
         variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0)
+        units = ((Cout + 63) // 64) * ((Cin + 63) // 64) * ((B * ((T + 31) // 32) + 1) // 2)
+        if units >= WGRAD_SOLO_UNITS:
+            variant = (variant, len(self.jobs))  # a queue of its own, submitted right away
         queue = self.pending.setdefault(variant, [])
         queue.append((job, (x, gy, mask_y, mask_drop, ws), (w, bias)))
         self.stream = _stream()
         if not self.queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self.queued = True
-        if len(queue) >= WGRAD_GROUP:
+        if len(queue) >= WGRAD_GROUP or units >= WGRAD_SOLO_UNITS:
             self.submit(variant)
 
     def submit(self, variant=None):
