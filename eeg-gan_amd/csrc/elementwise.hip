@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __rest
 // sample.  The host picks (W, CG) so that even the short early stages (T = 32..256) spread over the
 // chip: fewer units per workgroup and more channel groups mean more workgroups and a shorter
 // sequential channel loop per thread.
-template <int W, int CG>
+// CPT > 0: the channel count is CG * CPT and a thread keeps its CPT values in registers between the
+// reduction and the scaling (one read of the input instead of two; all its loads are issued up front).
+template <int W, int CG, int CPT>
 __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ h, const float* __restrict__ drop,
                                                             float* __restrict__ y, float* __restrict__ d, int B, int C,
                                                             int T, float eps) {
@@ -58,7 +60,19 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
     float s[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
-    if (ok) {
+    f32x4 keep[CPT > 0 ? CPT : 1];
+    if (CPT > 0) {
+        static_assert(CPT == 0 || W == 4, "register-resident form is for the float4 path");
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                keep[i] = *reinterpret_cast<const f32x4*>(h + ((long long)b * C + cg + i * CG) * T + t);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+#pragma unroll
+                for (int k = 0; k < W; ++k) s[k] += keep[i][k] * keep[i][k];
+        }
+    } else if (ok) {
         for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
             if (W == 4) {
@@ -87,6 +101,18 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < W; ++k) d[(long long)b * T + t + k] = dv[k];
     }
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = cg + i * CG;
+            const float r = drop ? drop[b * C + c] : 1.f;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < W; ++k) o[k] = keep[i][k] * dv[k] * r;
+            *reinterpret_cast<f32x4*>(y + ((long long)b * C + c) * T + t) = o;
+        }
+        return;
+    }
     for (int c = cg; c < C; c += CG) {
         const long long off = ((long long)b * C + c) * T + t;
         const float r = drop ? drop[b * C + c] : 1.f;
@@ -102,7 +128,7 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
     }
 }
 
-template <int W, int CG>
+template <int W, int CG, int CPT>
 __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const float* __restrict__ drop, const float* __restrict__ d,
                                                             float* __restrict__ gc, int B, int C, int T, float slope) {
@@ -117,7 +143,22 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
     float s[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) s[k] = 0.f;
-    if (ok) {
+    f32x4 ka[CPT > 0 ? CPT : 1], kv[CPT > 0 ? CPT : 1];
+    if (CPT > 0) {
+        static_assert(CPT == 0 || W == 4, "register-resident form is for the float4 path");
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const long long off = ((long long)b * C + cg + i * CG) * T + t;
+                ka[i] = *reinterpret_cast<const f32x4*>(gy + off);
+                kv[i] = *reinterpret_cast<const f32x4*>(y + off);
+            }
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+#pragma unroll
+                for (int k = 0; k < W; ++k) s[k] += ka[i][k] * kv[i][k];
+        }
+    } else if (ok) {
         for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
             if (W == 4) {
@@ -142,6 +183,20 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
         for (int g = 0; g < CG; ++g) tot += red[g][ul][k];
         S[k] = tot / (float)C;
         dv[k] = d[(long long)b * T + t + k];
+    }
+    if (CPT > 0) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = cg + i * CG;
+            const float r = drop ? drop[b * C + c] : 1.f;
+            const float ir = 1.f / r;
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+                o[k] = dv[k] * (ka[i][k] * r - kv[i][k] * ir * S[k]) * (kv[i][k] > 0.f ? 1.f : slope);
+            *reinterpret_cast<f32x4*>(gc + ((long long)b * C + c) * T + t) = o;
+        }
+        return;
     }
     for (int c = cg; c < C; c += CG) {
         const long long off = ((long long)b * C + c) * T + t;
@@ -271,12 +326,22 @@ extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, floa
     const bool vec = (T % 4 == 0) && aligned16(h) && aligned16(y) && aligned16(d);
     const PnCfg c = pn_config((long long)B * T, vec);
     hipStream_t st = as_stream(stream);
-    if (c.w == 4 && c.cg == 4)
-        hipLaunchKernelGGL((pixelnorm_fwd_kernel<4, 4>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
-    else if (c.w == 4)
-        hipLaunchKernelGGL((pixelnorm_fwd_kernel<4, 16>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
-    else
-        hipLaunchKernelGGL((pixelnorm_fwd_kernel<1, 16>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps);
+#define PN_FWD(W, CG, CPT) \
+    hipLaunchKernelGGL((pixelnorm_fwd_kernel<W, CG, CPT>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps)
+    const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;  // channels per thread, register-resident when small
+    if (c.w == 4 && c.cg == 4) {
+        if (cpt == 16) PN_FWD(4, 4, 16);
+        else if (cpt == 32) PN_FWD(4, 4, 32);
+        else PN_FWD(4, 4, 0);
+    } else if (c.w == 4) {
+        if (cpt == 4) PN_FWD(4, 16, 4);
+        else if (cpt == 8) PN_FWD(4, 16, 8);
+        else if (cpt == 16) PN_FWD(4, 16, 16);
+        else PN_FWD(4, 16, 0);
+    } else {
+        PN_FWD(1, 16, 0);
+    }
+#undef PN_FWD
     return check_launch("pixelnorm_drop_fwd");
 }
 
@@ -287,15 +352,22 @@ extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const 
     const bool vec = (T % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
     const PnCfg c = pn_config((long long)B * T, vec);
     hipStream_t st = as_stream(stream);
-    if (c.w == 4 && c.cg == 4)
-        hipLaunchKernelGGL((pixelnorm_bwd_kernel<4, 4>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
-                           slope);
-    else if (c.w == 4)
-        hipLaunchKernelGGL((pixelnorm_bwd_kernel<4, 16>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
-                           slope);
-    else
-        hipLaunchKernelGGL((pixelnorm_bwd_kernel<1, 16>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T,
-                           slope);
+#define PN_BWD(W, CG, CPT)                                                                                     \
+    hipLaunchKernelGGL((pixelnorm_bwd_kernel<W, CG, CPT>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T, \
+                       slope)
+    const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;
+    if (c.w == 4 && c.cg == 4) {
+        if (cpt == 16) PN_BWD(4, 4, 16);
+        else PN_BWD(4, 4, 0);
+    } else if (c.w == 4) {
+        if (cpt == 4) PN_BWD(4, 16, 4);
+        else if (cpt == 8) PN_BWD(4, 16, 8);
+        else if (cpt == 16) PN_BWD(4, 16, 16);
+        else PN_BWD(4, 16, 0);
+    } else {
+        PN_BWD(1, 16, 0);
+    }
+#undef PN_BWD
     return check_launch("pixelnorm_drop_bwd");
 }
 

@@ -96,6 +96,6 @@ def run(B):
     row("x_hat mix [B,5,1920]", timeit(lambda: ops.mix_batch_raw(real, fake, mix), n), nbytes=3.0 * 4 * B * 5 * T)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # (importable: bench_hbm.py reuses timeit/row)
     for B in ([int(a) for a in sys.argv[1:]] or [32, 512]):
         run(B)
