@@ -235,7 +235,7 @@ WGRAD_GROUP = int(os.environ.get("EEGGAN_WGRAD_GROUP", "16"))
 # ... unless the layer keeps the chip busy for many rounds by itself (work units = 64x64-channel regions x
 # pairs of 32-sample subtiles; 256 workgroups take one unit each per round): grouping then only delays
 # the launch and holds on to the layer's activations (measured at 512 samples per GPU: 4 % slower grouped).
-WGRAD_SOLO_UNITS = 8 * 256
+WGRAD_SOLO_UNITS = 16 * 256
 
 
 class _DirectGrads:
