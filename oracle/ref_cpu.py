@@ -278,17 +278,42 @@ def minibatch_stddev(x, group_size: int = 4, window: int = 32):
 
 
 # --------------------------------------------------------------------------- networks
+def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", first: bool = False,
+            last: bool = False):
+    """GBlock.forward, network.py:206-218 (no residual, not deep): two GeneralConvs with pixel norm and
+    GDrop, the first one with the full-length kernel and pad = k-1 in the first block (network.py:157-159);
+    ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
+    ls = dict(act_alpha=cfg.act_alpha, norm="pixel", drop=cfg.g_dropout, src=src)
+    h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
+    h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
+    if last:
+        return torch.tanh(general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1) * cfg.tanh_scale)
+    return h
+
+
+def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", first: bool = False):
+    """DBlock.forward, network.py:441-449 (no residual, not deep): optional from_rgb (1x1 conv + LeakyReLU,
+    network.py:428-429), then two GeneralConvs with GDrop; the last block of the list prepends
+    MinibatchStddev and ends in the full-length kernel without padding (network.py:403-418)."""
+    ls = dict(act_alpha=cfg.act_alpha, norm=None, drop=cfg.d_dropout, src=src)
+    if first:
+        h = general_conv(h, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
+    if pos == cfg.num_stages:
+        h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
+        h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+        return general_conv(h, params, scales, f"blocks.{pos}.net.2", pad=0, **ls)
+    h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
+    return general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+
+
 def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfig,
                       src: Optional[DropSource] = None):
     """network.py:354-396 (default options: pggan rgb mode, pixel norm,
     normalize_latents, no conditioning).  Returns x[B, 5, T(depth)]."""
     src = src or DropSource("off")
-    ls = dict(act_alpha=cfg.act_alpha, norm="pixel", drop=cfg.g_dropout, src=src)
 
     def gblock(prefix, h, first=False):
-        h = general_conv(h, params, scales, f"{prefix}.convs.0",
-                         pad=cfg.initial_kernel_size - 1 if first else None, **ls)
-        return general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
+        return g_block(params, scales, prefix, h, cfg, src, first=first)
 
     def to_rgb(prefix, h):
         c = general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1)
@@ -314,18 +339,12 @@ def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetC
     """network.py:528-560 (default options).  Returns (score[B], h[B, 256, 1])."""
     src = src or DropSource("off")
     R = cfg.num_stages
-    ls = dict(act_alpha=cfg.act_alpha, norm=None, drop=cfg.d_dropout, src=src)
 
     def from_rgb(pos, v):
         return general_conv(v, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
 
     def dblock(pos, h):
-        if pos == R:
-            h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
-            h = general_conv(h, params, scales, f"blocks.{R}.net.1", **ls)
-            return general_conv(h, params, scales, f"blocks.{R}.net.2", pad=0, **ls)
-        h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
-        return general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+        return d_block(params, scales, pos, h, cfg, src)
 
     first = R - depth                      # blocks[-(depth+1)]
     h = dblock(first, from_rgb(first, x))

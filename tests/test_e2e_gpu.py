@@ -198,6 +198,30 @@ def ops_mean_neg(v):
     return ops.mean_scale(v, -1.0)
 
 
+def test_blocks_against_reference_fixture(dev):
+    """One GBlock / DBlock at a time (reference network.py:206-218, 441-449) with the reference's GDrop
+    draws: head block, a block with to_rgb, a wide block; first block with from_rgb, a middle block, the
+    last block with MinibatchStddev and the full-length kernel.  Outputs to 1e-5 and input gradients to 1e-4
+    of the reference (either precision; measured 2e-7 .. 5e-7 for both)."""
+    from eeggan_amd import config
+    from helpers import block_inputs
+    fx = load_fixture("blocks")
+    g, d = _build(dev, 0, 1.0, config.RANDOM_SEED)
+    g, d = g.to(dev), d.to(dev)
+    for (name, net, path, kw, _), x, gy in block_inputs(fx):
+        block = (g if net == "g" else d).get_submodule(path)
+        np.random.seed(int(fx[f"{name}_seed"]))
+        xi = x.to(dev).requires_grad_(True)
+        y = block(xi, **kw)
+        (gx,) = torch.autograd.grad(y, xi, gy.to(dev))
+        assert tuple(y.shape) == tuple(int(v) for v in fx[f"{name}_yshape"])
+        ey = min(rel(subsample(y, 4096), fx[f"{name}_y64"]), rel(subsample(y, 4096), fx[f"{name}_y32"]))
+        eg = min(rel(subsample(gx, 4096), fx[f"{name}_gx64"]), rel(subsample(gx, 4096), fx[f"{name}_gx32"]))
+        print(f"block {name}: output {ey:.1e}, input gradient {eg:.1e}")
+        assert ey < 1e-5, (name, ey)
+        assert eg < 1e-4, (name, eg)
+
+
 def test_against_oracle_other_config(dev):
     """A configuration no fixture holds (depth 3, alpha 0.7, B=8), against the fp64 oracle run here."""
     from eeggan_amd import config, losses

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_weights, load_fixture, oracle_params, rel, subsample
+from helpers import block_inputs, check_weights, load_fixture, oracle_params, rel, subsample
 from oracle import ref_cpu as O
 
 
@@ -103,3 +103,26 @@ def test_real_data_side_matches_reference_dataset():
             assert tuple(got.shape) == fx[key].shape == (3, 5, O.NetConfig().seq_len(depth))
             worst = max(worst, rel(got, fx[key]))
     assert worst < 1e-4, worst
+
+
+def test_blocks_match_reference():
+    """GBlock / DBlock forward and input gradient (reference network.py:206-218, 441-449) on the default
+    networks with seeded GDrop draws: the oracle's blocks against the reference's fp64 run (1e-6: the
+    re-drawn fp32 inputs are reproducible to ~1 ulp)."""
+    from eeggan_amd import config
+    fx = load_fixture("blocks")
+    g, d = config.build_models(config.RANDOM_SEED)
+    cfg = O.NetConfig()
+    for (name, net, path, kw, _), x, gy in block_inputs(fx):
+        params, scales = oracle_params(g if net == "g" else d)
+        np.random.seed(int(fx[f"{name}_seed"]))
+        src = O.DropSource("numpy")
+        xi = x.double().requires_grad_(True)
+        if net == "g":
+            y = O.g_block(params, scales, path, xi, cfg, src, first=(path == "block0"), last=kw["last"])
+        else:
+            y = O.d_block(params, scales, int(path.split(".")[1]), xi, cfg, src, first=kw["first"])
+        (gx,) = torch.autograd.grad(y, xi, gy.double())
+        assert tuple(y.shape) == tuple(int(v) for v in fx[f"{name}_yshape"])
+        assert rel(subsample(y, 4096), fx[f"{name}_y64"]) < 1e-6, name
+        assert rel(subsample(gx, 4096), fx[f"{name}_gx64"]) < 1e-6, name

@@ -443,6 +443,66 @@ def dataset_fixture(out_dir):
     print("dataset_ops.npz:", len(fx), "arrays")
 
 
+# ------------------------------------------------------------------------------------------ blocks
+BLOCK_CASES = (
+    # name, network, module path, kwargs of forward, input shape (B, C, T)
+    ("g_head", "g", "block0", dict(last=False), (8, 256, 1)),
+    ("g_mid_rgb", "g", "blocks.3", dict(last=True), (4, 64, 768)),
+    ("g_wide", "g", "blocks.1", dict(last=False), (4, 256, 256)),
+    ("d_first", "d", "blocks.1", dict(first=True), (4, 5, 1280)),
+    ("d_mid", "d", "blocks.4", dict(first=False), (4, 64, 512)),
+    ("d_last", "d", "blocks.7", dict(first=False), (8, 256, 32)),
+)
+
+
+def block_fixture(out_dir, seed=21):
+    """GBlock.forward / DBlock.forward of the reference (network.py:206-218, 441-449) on the seed-initialised
+    default networks, with the GDrop draws of the numpy stream seeded per case: inputs, outputs and input
+    gradients in fp64 and fp32."""
+    import copy
+    g_ref, d_ref = build_pair(cfgmod.RANDOM_SEED)
+    fx = {"generator_seed": np.array(seed)}
+    gen = torch.Generator().manual_seed(seed)
+    cfg = O.NetConfig()
+    for n, (name, net, path, kw, shape) in enumerate(BLOCK_CASES):
+        model = g_ref if net == "g" else d_ref
+        block = model.get_submodule(path)
+        x = torch.randn(*shape, generator=gen)
+        gy = None
+        outs = {}
+        for dtype, tag in ((torch.float64, "64"), (torch.float32, "32")):
+            blk = copy.deepcopy(block).to(dtype)
+            xi = x.detach().clone().to(dtype).requires_grad_(True)
+            np.random.seed(seed + n)
+            y = blk(xi, **kw)
+            if gy is None:
+                gy = torch.randn(y.shape, generator=gen)
+            (gx,) = torch.autograd.grad(y, xi, gy.to(dtype))
+            outs[tag] = (y.detach(), gx)
+        # the oracle's block against the reference's, same draws
+        params, scales = to_oracle(model, torch.float64)
+        np.random.seed(seed + n)
+        src = O.DropSource("numpy")
+        if net == "g":
+            yo = O.g_block(params, scales, path, x.double(), cfg, src, first=(path == "block0"), last=kw["last"])
+        else:
+            yo = O.d_block(params, scales, int(path.split(".")[1]), x.double(), cfg, src, first=kw["first"])
+        err = rel(yo.detach(), outs["64"][0])
+        assert err < 1e-12, (name, err)
+        # inputs are re-drawn by the tests (same generator, same order); outputs are kept as 4096 samples
+        fx[f"{name}_x_check"] = np.array([float(x.double().sum()), float((x.double() ** 2).sum())])
+        fx[f"{name}_gy_check"] = np.array([float(gy.double().sum()), float((gy.double() ** 2).sum())])
+        fx[f"{name}_yshape"] = np.array(outs["64"][0].shape)
+        fx[f"{name}_y64"], fx[f"{name}_gx64"] = subsample(outs["64"][0], 4096), subsample(outs["64"][1], 4096)
+        fx[f"{name}_y32"], fx[f"{name}_gx32"] = subsample(outs["32"][0], 4096), subsample(outs["32"][1], 4096)
+        fx[f"{name}_ynorm"] = np.array(float(outs["64"][0].double().norm()))
+        fx[f"{name}_gxnorm"] = np.array(float(outs["64"][1].double().norm()))
+        fx[f"{name}_seed"] = np.array(seed + n)
+        print(f"  {name}: y {tuple(outs['64'][0].shape)}, fp32 vs fp64 {rel(outs['32'][0], outs['64'][0]):.1e}")
+    np.savez_compressed(os.path.join(out_dir, "blocks.npz"), **fx)
+    print("blocks.npz:", len(fx), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -459,6 +519,7 @@ def main():
         "e2e_d7f": lambda: e2e_fixture(args.out, "e2e_d7_a05", 7, 0.5, 4, 105),
         "step": lambda: step_fixture(args.out),
         "dataset": lambda: dataset_fixture(args.out),
+        "blocks": lambda: block_fixture(args.out),
     }
     for k, fn in jobs.items():
         if not args.only or k in args.only.split(","):
