@@ -144,8 +144,8 @@ struct XStage {
 //   plus wave-uniform chunk offsets);  KS (1|2): the waves split each chunk's reduction indices KS
 //   ways and sum their accumulators through LDS before the epilogue -- for layers with so few
 //   (b, t) positions (T = 32) that the tile has to be one subtile wide to give every CU work.
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, int NTHR = 64 * WM * WN * KS>
+__global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
     constexpr int XLD = NT * SUB;
@@ -153,13 +153,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     constexpr int RN = NT / WN;
     constexpr int KH = CK / 2 * K;      // k-steps per chunk (each MFMA consumes 2 reduction indices)
     constexpr int WQ = CK * K / 4;      // float4 per weight row of a chunk
-    constexpr int WV = CT * WQ / 256;   // float4 weight items per thread
-    constexpr int XV = CK * NT * 8 / 256;  // float4 activation items per thread (= NT)
-    constexpr int XROWS = 32 / NT;      // activation rows covered per pass of the 256 threads
-    constexpr int HROWS = 128 / NT;     // halo rows covered per pass
+    constexpr int WV = CT * WQ / NTHR;  // float4 weight items per thread
+    constexpr int XV = CK * NT * 8 / NTHR;  // float4 activation items per thread
+    constexpr int XROWS = NTHR / 8 / NT;    // activation rows covered per pass of the workgroup's threads
+    constexpr int HROWS = NTHR / 2 / NT;    // halo rows covered per pass
     constexpr int HV = (CK + HROWS - 1) / HROWS;
     constexpr int BUF = CT * WLD + CK * XLD;
-    static_assert(WM * WN * KS == 4 && KH % (4 * KS) == 0 && (CT * WQ) % 256 == 0, "tile shape");
+    static_assert((NTHR == 256 || NTHR == 512) && KH % (4 * KS) == 0 && (CT * WQ) % NTHR == 0 && XV >= 1 &&
+                      (CK * NT * 8) % NTHR == 0, "tile shape");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvArgs a) {
     int w_row[WV], w_q[WV];
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-        const int e4 = tid + 256 * i;
+        const int e4 = tid + NTHR * i;
         w_row[i] = e4 / WQ;
         w_q[i] = e4 - w_row[i] * WQ;
     }
@@ -636,18 +637,18 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
             return 1;
         }
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 256, lds) != hipSuccess || n < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 64 * WM * WN * KS, lds) != hipSuccess || n < 1)
             n = 1;
         per_cu = n > 4 ? 4 : n;
     }
     const long long ntiles = (long long)((a.NS + NT - 1) / NT) * ((a.Cout + CT - 1) / CT);
     long long grid = (long long)num_cus() * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * WM * WN * KS), lds, st, a);
     return check_launch("conv1d");
 }
 
-// Tile choice: four subtiles per workgroup while that still gives every CU a workgroup.  The short
+// Tile choice: four subtiles per workgroup (one workgroup per CU) while that still gives every CU a workgroup.  The short
 // wide layers of the path (T = 32 .. 256 at 128-256 channels, 64 .. 512 subtiles) do not: they take a
 // one-subtile tile whose four waves split the reduction, small enough in LDS for two workgroups per
 // CU.  (Measured in the captured training step against a two-subtile tile without the split:
@@ -663,8 +664,8 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
     if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
     const bool full = a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.T % 32 == 0;
-    if (tiles(64, 4) >= num_cus())
-        return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
+    if (tiles(64, 4) >= num_cus())  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
+        return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
     return full ? launch_fwd<K, 64, 1, 32, 2, 1, true, true, 2>(a, st) : launch_fwd<K, 64, 1, 32, 2, 1, true, false, 2>(a, st);
 }
 
