@@ -664,7 +664,11 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
     if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
     const bool full = a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.T % 32 == 0;
-    if (tiles(64, 4) >= num_cus())  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
+    // Rounds of the chip each tile needs (a round of four-subtile tiles is twice as long as a round of pairs of
+    // one-subtile tiles): batches that are not a multiple of the chip width lose up to half a round on the big tile.
+    const long long cus = num_cus();
+    const long long cost4 = (tiles(64, 4) + cus - 1) / cus * 4 * 20, cost1 = (tiles(64, 1) + 2 * cus - 1) / (2 * cus) * 2 * 21;
+    if (tiles(64, 4) >= cus && cost4 <= cost1)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
         return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
     return full ? launch_fwd<K, 64, 1, 32, 2, 1, true, true, 2>(a, st) : launch_fwd<K, 64, 1, 32, 2, 1, true, false, 2>(a, st);
 }
