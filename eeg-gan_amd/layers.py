@@ -63,7 +63,7 @@ class _DropPool:
     written again after it is filled, so slices saved for backward stay valid; ``reset`` drops the
     current chunk so that an iteration (and a captured graph of it) starts with a fresh draw."""
 
-    CHUNK = 1 << 17
+    CHUNK = 1 << 18  # one critic iteration at the final stage takes ~190 000 multipliers
 
     def __init__(self):
         self._chunks = {}

@@ -117,7 +117,7 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         x_hat = xin[2 * n:].detach().requires_grad_(True)
         (scores, pred_hat), _, _ = dis(ops.Parts([xin[:2 * n], x_hat], [2, 1]))
         g = calc_grad(x_hat, pred_hat).view(n, -1)
-        return ops.wgan_gp_d_loss(scores[:n], scores[n:], g, iwass_drift_epsilon, grad_lambda, iwass_target)
+        return ops.wgan_gp_d_loss_stacked(scores, g, iwass_drift_epsilon, grad_lambda, iwass_target)
     if stack_real_fake:
         # one critic pass over [reals; fakes]: half the launches, twice the work per launch, and one
         # gradient contribution per weight instead of two.  The reference evaluates the two passes
@@ -133,7 +133,11 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         n = real_x.size(0)
         with layers.batch_segments(2):
             scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
-        d_real, d_fake = scores[:n], scores[n:]
+        alpha = get_mixing_factor(n) if mixing is None else mixing
+        x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
+        pred_hat, _, _ = dis(x_hat)
+        g = calc_grad(x_hat["x"], pred_hat).view(n, -1)
+        return ops.wgan_gp_d_loss_stacked(scores, g, iwass_drift_epsilon, grad_lambda, iwass_target)
     else:
         d_real, _, _ = dis(real)
         if fake is None:

@@ -1119,6 +1119,44 @@ class _WganGpLoss(Function):
         return g_r, g_f, g_g, None, None, None
 
 
+class _WganGpLossStacked(Function):
+    """The same loss on the scores of a stacked critic pass ([reals; fakes] in one tensor): one gradient
+    tensor goes back instead of two slices (whose backward costs autograd two zero fills, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, scores, g, drift, lam, target):
+        scores, g = _chk(scores, "scores"), _chk(g, "penalty gradient")
+        B = scores.numel() // 2
+        if scores.numel() != 2 * B or g.shape[0] != B:
+            raise RuntimeError("wgan_gp_d_loss_stacked: scores must hold the reals' and the fakes' scores")
+        per = g.numel() // B
+        norms = torch.empty((B,), device=g.device, dtype=torch.float32)
+        loss = torch.empty((), device=g.device, dtype=torch.float32)
+        call("eeggan_wgan_gp_loss_fwd", scores.data_ptr(), scores.data_ptr() + 4 * B, g.data_ptr(), norms.data_ptr(),
+             loss.data_ptr(), B, per, drift, lam, target, _stream())
+        ctx.save_for_backward(scores, g, norms)
+        ctx.cfg = (drift, lam, target)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        scores, g, norms = ctx.saved_tensors
+        drift, lam, target = ctx.cfg
+        gl = _chk(gl, "loss grad")
+        B = scores.numel() // 2
+        per = g.numel() // B
+        g_s, g_g = torch.empty_like(scores), torch.empty_like(g)
+        call("eeggan_wgan_gp_loss_bwd", gl.data_ptr(), scores.data_ptr(), g.data_ptr(), norms.data_ptr(),
+             g_s.data_ptr(), g_s.data_ptr() + 4 * B, g_g.data_ptr(), B, per, drift, lam, target, _stream())
+        return g_s, g_g, None, None, None
+
+
+def wgan_gp_d_loss_stacked(scores, g, drift, lam, target):
+    """``wgan_gp_d_loss(scores[:B], scores[B:], ...)`` without slicing the scores."""
+    return _WganGpLossStacked.apply(scores, g, float(drift), float(lam), float(target))
+
+
 def wgan_gp_d_loss(d_real, d_fake, g, drift, lam, target):
     """mean(d_fake) - mean(d_real) + drift*mean(d_real^2) + lam/target^2 * mean((|g_b| - target)^2)."""
     return _WganGpLoss.apply(d_real, d_fake, g, float(drift), float(lam), float(target))
