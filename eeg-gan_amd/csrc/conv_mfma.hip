@@ -658,7 +658,9 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     const long long ns = a.NS;
     auto tiles = [&](int ct, int nt) { return ((ns + nt - 1) / nt) * ((a.Cout + ct - 1) / ct); };
     {
-        const int rc = launch_conv_ws(a, K, st);
+        int rc = launch_conv_thin(a, K, st);
+        if (rc >= 0) return rc;
+        rc = launch_conv_ws(a, K, st);
         if (rc >= 0) return rc;
     }
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);

@@ -96,6 +96,43 @@ def test_conv_fwd_dgrad_wgrad(dev, B, Cin, Cout, T, K):
     assert rel(om, conv_ref(q, w, None, scale, pad) * mask) < TOL
 
 
+@pytest.mark.parametrize("Cin,Cout", [(5, 64), (64, 5), (8, 8)])
+def test_conv_thin_large_batch(dev, Cin, Cout):
+    """1x1 convs with at most 8 channels on one side run a bandwidth-bound kernel of their own once the
+    batch is large (B*T/4 >= 2 workgroups per CU); all epilogues and the fused input mask, checked on the
+    first and last samples against the fp64 reference."""
+    ops = _ops()
+    B, T = 288, 1920
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 1, generator=g)
+    b = torch.randn(Cout, generator=g)
+    drop = torch.rand(B, Cout, generator=g) + 0.5
+    my = torch.randn(B, Cin, T, generator=g)
+    md = torch.rand(B, Cin, generator=g) + 0.5
+    aux = torch.randn(B, Cout, T, generator=g)
+    xd, wd, bd, dd, myd, mdd, auxd = (t.to(dev) for t in (x, w, b, drop, my, md, aux))
+    sel = [0, 1, 2, B - 2, B - 1]
+    scale = 0.37
+    cases = {
+        "lrelu+drop": (dict(act=1, act_param=0.2), lambda: conv_ref(x[sel], w, b, scale, 0, drop[sel], "lrelu")),
+        "tanh": (dict(act=2, act_param=0.5), lambda: conv_ref(x[sel], w, b, scale, 0, None, "tanh")),
+        "linear": (dict(), lambda: conv_ref(x[sel], w, b, scale, 0)),
+    }
+    for name, (kw, ref) in cases.items():
+        y = ops.conv1d_raw(xd, wd, bd, dd if name == "lrelu+drop" else None, in_scale=scale, **kw)
+        assert rel(y[sel], ref()) < TOL, name
+    # fused input mask (a gradient entering through the LeakyReLU/GDrop of the layer below) and output mask
+    xm = x[sel].double() * torch.where(my[sel] > 0, 1.0, 0.2).double() * md[sel].double()[:, :, None]
+    ref = F.conv1d(xm * scale, w.double(), None)
+    y = ops.conv1d_raw(xd, wd, None, None, in_scale=scale, mask_y=myd, mask_drop=mdd, mask_slope=0.2)
+    assert rel(y[sel], ref) < TOL
+    refm = F.conv1d(x[sel].double() * scale, w.double(), None) * torch.where(aux[sel] > 0, 1.0, 0.2).double() \
+        * drop[sel].double()[:, :, None]
+    y = ops.conv1d_raw(xd, wd, None, dd, in_scale=scale, act=3, act_param=0.2, act_aux=auxd)
+    assert rel(y[sel], refm) < TOL
+
+
 def test_conv_wgrad_deterministic(dev):
     ops = _ops()
     x = torch.randn(8, 64, 768, device=dev)
