@@ -54,6 +54,7 @@ SIGNATURES = {
     "eeggan_mix_batch": (_i, [_f, _f, _f, _f, _i, _sz, _st]),
     "eeggan_pow_base": (_i, [_f, _f, _sz, _fl, _st]),
     "eeggan_resample": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "eeggan_resample_quads": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "eeggan_mbstd_workspace": (_sz, [_i, _i, _i, _i]),
     "eeggan_mbstd_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),

@@ -37,6 +37,60 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     }
 }
 
+// Quad form: a thread produces 4 consecutive output positions (one 16-byte store per row).  Their taps
+// fall into a span of at most 4*NV input samples starting at base[q] (a multiple of 4), which the thread
+// loads as NV 16-byte vectors; the host hands the taps over as a dense 4 x (4*NV) coefficient block per
+// quad (zeros where there is no tap), so no address depends on a table value except through base[q].
+// Summation runs over the span in ascending input position: the order of resample_kernel's sorted taps,
+// with exact zero terms in between (the two agree up to the fusing of multiply-adds, ~1 ulp).
+constexpr int RQ_ROWS = 8;
+
+template <int NV>
+__global__ __launch_bounds__(256) void resample_quad_kernel(const float* __restrict__ x, const int32_t* __restrict__ base,
+                                                            const float* __restrict__ coef, float* __restrict__ out,
+                                                            long long rows, int Tin, int Tout, int chunks) {
+    // threads are dealt out over (row group, quad) without regard to workgroup borders: Tout/4 is rarely a
+    // multiple of 256 (320 at Tout = 1280), and a grid with one axis per row would idle the remainder
+    const int NQ = Tout / 4;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rg = id / NQ;
+    const int q = (int)(id - rg * NQ);
+    // a thread takes `chunks` x RQ_ROWS consecutive rows: its coefficient block (as many bytes as 8 rows of
+    // data) is loaded once for all of them
+    long long r0 = rg * RQ_ROWS * chunks;
+    if (r0 >= rows) return;
+    const int b0 = base[q];
+    f32x4 cf[4][NV];  // cf[e][v][i]: weight of input b0 + 4v + i in output 4q + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            cf[e][v] = *reinterpret_cast<const f32x4*>(coef + ((long long)q * 4 + e) * (4 * NV) + 4 * v);
+    for (int ch = 0; ch < chunks && r0 < rows; ++ch, r0 += RQ_ROWS) {
+    f32x4 xv[RQ_ROWS][NV];
+#pragma unroll
+    for (int r = 0; r < RQ_ROWS; ++r) {
+        const long long row = r0 + r < rows ? r0 + r : rows - 1;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[r][v] = *reinterpret_cast<const f32x4*>(x + row * Tin + b0 + 4 * v);
+    }
+#pragma unroll
+    for (int r = 0; r < RQ_ROWS; ++r) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += cf[e][v][i] * xv[r][v][i];
+            o[e] = s;
+        }
+        if (r0 + r < rows) *reinterpret_cast<f32x4*>(out + (r0 + r) * Tout + 4 * q) = o;
+    }
+    }
+}
+
 // ---- minibatch stddev --------------------------------------------------------------------------
 // Group member m owns the G samples b = g*M + m; n = C*T elements per sample.  The element axis is
 // cut into chunks of MB_CHUNK so that the grid (M x chunks) fills the chip (M is only B/4); sums over
@@ -220,6 +274,32 @@ extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* 
     }
 #undef RS_CASE
     return check_launch("resample");
+}
+
+extern "C" int eeggan_resample_quads(const float* x, const int32_t* base, const float* coef, float* out, size_t rows,
+                                     int Tin, int Tout, int nv, void* stream) {
+    EEGGAN_REQUIRE(x && base && coef && out, "resample_quads: null pointer");
+    EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample_quads: non-positive dimension");
+    EEGGAN_REQUIRE(nv >= 1 && nv <= 4, "resample_quads: nv %d outside [1, 4]", nv);
+    EEGGAN_REQUIRE(Tin % 4 == 0 && Tout % 4 == 0 && Tin >= 4 * nv,
+                   "resample_quads: lengths %d -> %d must be multiples of 4 and the input at least %d long", Tin, Tout,
+                   4 * nv);
+    EEGGAN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                     reinterpret_cast<uintptr_t>(coef)) & 15) == 0,
+                   "resample_quads: x, out and coef must be 16-byte aligned");
+    const int chunks = rows >= 16384 ? 4 : 1;  // (large batches: more rows per coefficient block)
+    const size_t per = (size_t)RQ_ROWS * chunks;
+    const size_t threads = (rows + per - 1) / per * (size_t)(Tout / 4);
+    EEGGAN_REQUIRE(threads < ((size_t)1 << 39), "resample_quads: too many rows");
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipStream_t st = as_stream(stream);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(resample_quad_kernel<1>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 2: hipLaunchKernelGGL(resample_quad_kernel<2>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 3: hipLaunchKernelGGL(resample_quad_kernel<3>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        default: hipLaunchKernelGGL(resample_quad_kernel<4>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+    }
+    return check_launch("resample_quads");
 }
 
 extern "C" size_t eeggan_mbstd_workspace(int B, int C, int T, int group) {

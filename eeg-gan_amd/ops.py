@@ -912,9 +912,12 @@ def pixel_norm(h):
 
 
 # --------------------------------------------------------------------------------------- linear helpers
+USE_RESAMPLE_QUADS = os.environ.get("EEGGAN_RESAMPLE_QUADS", "1") != "0"  # (comparison switch)
+
+
 def _gather_raw(x, table, out=None):
     x = _chk(x, "resample x")
-    idx, coef, t_in, t_out, taps = table
+    idx, coef, t_in, t_out, taps, quads = table
     if x.shape[-1] != t_in:
         raise RuntimeError(f"resample: input length {x.shape[-1]} does not match the table ({t_in})")
     rows = x.numel() // t_in
@@ -922,8 +925,13 @@ def _gather_raw(x, table, out=None):
         out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
     elif tuple(out.shape) != tuple(x.shape[:-1]) + (t_out,) or not out.is_contiguous():
         raise RuntimeError("resample: out does not match the result shape")
-    call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
-         taps, _stream())
+    if quads is not None and USE_RESAMPLE_QUADS and (x.data_ptr() | out.data_ptr()) % 16 == 0:
+        qbase, qcoef, nv = quads  # 16-byte accesses, four outputs per thread
+        call("eeggan_resample_quads", x.data_ptr(), qbase.data_ptr(), qcoef.data_ptr(), out.data_ptr(), rows, t_in,
+             t_out, nv, _stream())
+    else:
+        call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
+             taps, _stream())
     return out
 
 

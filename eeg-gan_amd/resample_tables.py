@@ -60,8 +60,40 @@ def _pack(rows, n_cols_unused=None):
     return idx, coef, taps
 
 
+QUAD_MAX_NV = 4
+
+
+def _pack_quads(rows, t_in: int):
+    """Quad form of a sparse-row table (see ``eeggan_resample_quads``): per 4 consecutive output
+    positions the first input sample of their span (a multiple of 4, moved left at the right edge so
+    that the span stays inside the row) and a dense 4 x 4nv block of weights, nv the widest span of the
+    table in 16-byte vectors.  None when the operator is not local enough or a length is no multiple of 4."""
+    t_out = len(rows)
+    if t_out % 4 or t_in % 4 or t_out == 0:
+        return None
+    spans = []
+    for q in range(t_out // 4):
+        keys = [i for r in rows[4 * q:4 * q + 4] for i in r]
+        lo, hi = (min(keys), max(keys)) if keys else (0, 0)
+        spans.append((lo // 4 * 4, hi))
+    nv = max((hi - b) // 4 + 1 for b, hi in spans)
+    if nv > QUAD_MAX_NV or t_in < 4 * nv:
+        return None
+    base = np.zeros(t_out // 4, dtype=np.int32)
+    coef = np.zeros((t_out // 4, 4, 4 * nv), dtype=np.float32)
+    for q, (b, hi) in enumerate(spans):
+        b = min(b, t_in - 4 * nv)
+        assert b >= 0 and b % 4 == 0 and hi < b + 4 * nv
+        base[q] = b
+        for e in range(4):
+            for i, c in rows[4 * q + e].items():
+                coef[q, e, i - b] = c
+    return base, coef, nv
+
+
 def build_tables(t_in: int, p: int, q: int):
-    """(forward, transpose) tables as numpy arrays: each is (idx[int32], coef[float32], Tin, Tout, taps)."""
+    """(forward, transpose) tables as numpy arrays: each is (idx[int32], coef[float32], Tin, Tout, taps,
+    quads) with quads = (base[int32], coef[float32], nv) or None."""
     rows = composite_rows(t_in, p, q)
     t_out = len(rows)
     idx, coef, taps = _pack(rows)
@@ -70,7 +102,8 @@ def build_tables(t_in: int, p: int, q: int):
         for i, c in r.items():
             trans[i][m] = trans[i].get(m, 0.0) + c
     tidx, tcoef, ttaps = _pack(trans)
-    return (idx, coef, t_in, t_out, taps), (tidx, tcoef, t_out, t_in, ttaps)
+    return ((idx, coef, t_in, t_out, taps, _pack_quads(rows, t_in)),
+            (tidx, tcoef, t_out, t_in, ttaps, _pack_quads(trans, t_out)))
 
 
 _cache: Dict[Tuple, Tuple] = {}
@@ -83,7 +116,9 @@ def device_tables(t_in: int, p: int, q: int, device: torch.device):
     hit = _cache.get(key)
     if hit is None:
         f, b = build_tables(t_in, fr.numerator, fr.denominator)
-        up = lambda t: (torch.from_numpy(t[0]).to(device), torch.from_numpy(t[1]).to(device), t[2], t[3], t[4])
+        dv = lambda a: torch.from_numpy(a).to(device)
+        up = lambda t: (dv(t[0]), dv(t[1]), t[2], t[3], t[4],
+                        None if t[5] is None else (dv(t[5][0]), dv(t[5][1]), t[5][2]))
         hit = (up(f), up(b))
         _cache[key] = hit
     return hit

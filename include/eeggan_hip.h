@@ -180,6 +180,15 @@ int eeggan_pow_base(const float* n, float* out, size_t count, float base, void* 
  * transpose; both directions use this one gather kernel. */
 int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float* out,
                     size_t rows, int Tin, int Tout, int taps, void* stream);
+/* The same operator in quad form, for tables whose taps are local (every resampler of this path): a thread
+ * produces 4 consecutive outputs from the 4*nv input samples starting at base[q] (a multiple of 4, with
+ * base[q] + 4*nv <= Tin):  out[r, 4q+e] = sum_{j<4nv} coef[(4q+e)*4nv + j] * x[r, base[q] + j]  -- 16-byte
+ * loads and stores only, no address that depends on a table value but base.  Tin, Tout multiples of 4,
+ * nv in [1,4]; x, out, coef 16-byte aligned.  With the dense coefficients = the sparse ones laid out by
+ * input position it is the same sum in the same order as eeggan_resample (equal up to how the compiler
+ * fuses the multiply-adds: the last bit or two). */
+int eeggan_resample_quads(const float* x, const int32_t* base, const float* coef, float* out,
+                          size_t rows, int Tin, int Tout, int nv, void* stream);
 
 /* ---- MinibatchStddev (layers.py:67-90), one temporal window ------------------------------
  * fwd: out[B, C+1, T]: channels [0,C) = x, channel C = mean_{c,t} sqrt(mean_g (x - mean_g x)^2)

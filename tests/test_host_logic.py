@@ -89,17 +89,32 @@ def test_resample_tables_match_interpolate_then_pool():
                 y = F.interpolate(y, scale_factor=p, mode="linear", align_corners=False)
             if q != 1:
                 y = F.avg_pool1d(y, q, q, 0, False, True)
-            (idx, coef, a, b, taps), (tidx, tcoef, c, d, ttaps) = build_tables(t_in, p, q)
+            (idx, coef, a, b, taps, quads), (tidx, tcoef, c, d, ttaps, tquads) = build_tables(t_in, p, q)
             assert (a, b) == (t_in, y.shape[2]) and (c, d) == (y.shape[2], t_in) and taps <= 16 and ttaps <= 16
             got = (x.double()[..., idx.astype(np.int64)] * torch.from_numpy(coef).double()).sum(-1)
             assert float((got - y.double()).norm() / y.double().norm()) < 2e-6
+            # the quad form (dense 4 x 4nv blocks on 16-byte aligned spans) is the same operator
+            for (sidx, scoef, s_in, s_out), qd, src in (((idx, coef, a, b), quads, x), ((tidx, tcoef, c, d), tquads, None)):
+                if qd is None:
+                    continue
+                base, dense, nv = qd
+                assert base.shape == (s_out // 4,) and dense.shape == (s_out // 4, 4, 4 * nv) and 1 <= nv <= 4
+                assert (base % 4 == 0).all() and (base >= 0).all() and (base + 4 * nv <= s_in).all()
+                full = np.zeros((s_out, s_in))
+                for m in range(s_out):
+                    np.add.at(full[m], sidx[m], scoef[m].astype(np.float64))
+                qfull = np.zeros((s_out, s_in))
+                for qq in range(s_out // 4):
+                    qfull[4 * qq:4 * qq + 4, base[qq]:base[qq] + 4 * nv] = dense[qq]
+                assert np.array_equal(full, qfull)
+            assert quads is not None or t_in < 8  # every forward resampler of the schedule has a quad form
             # the transposed table is the adjoint: <A x, g> == <x, A^T g>
             g = torch.randn_like(y)
             back = (g.double()[..., tidx.astype(np.int64)] * torch.from_numpy(tcoef).double()).sum(-1)
             lhs, rhs = float((got * g.double()).sum()), float((x.double() * back).sum())
             assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
         T = T * up[i] // dn[i]
-    (idx, coef, a, b, taps), _ = build_tables(1, 4, 1)
+    (idx, coef, a, b, taps, _q), _ = build_tables(1, 4, 1)
     assert b == 4 and taps == 1 and coef.tolist() == [[1.0]] * 4
 
 

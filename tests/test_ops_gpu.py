@@ -304,6 +304,32 @@ def test_resample_all_ratios(dev):
     assert rel(resample_signal(x.to(dev), 1, 4), x.repeat(1, 1, 4)) == 0.0
 
 
+def test_resample_quad_form_matches_sparse_form(dev):
+    """The 16-byte quad kernel against the sparse-tap kernel (which the test above pins to the oracle), both
+    directions of every stage and their transposes, a row count that does not fill the last workgroup.  The
+    same taps in the same order; the compiler fuses the multiply-adds of the two loops differently, so the
+    results agree to the last bit or two (5e-7), not bit for bit."""
+    ops = _ops()
+    from eeggan_amd.resample_tables import device_tables
+    up, dn = [4, 2, 2, 3, 4, 5, 3], [1, 1, 1, 2, 3, 4, 2]
+    T, used = 32, 0
+    for i in range(7):
+        for p, q, t_in in ((up[i], dn[i], T), (dn[i], up[i], T * up[i] // dn[i])):
+            for table in device_tables(t_in, p, q, dev):
+                if table[5] is None:
+                    continue
+                x = torch.randn(3, 7, table[2], device=dev)
+                try:
+                    ops.USE_RESAMPLE_QUADS = False
+                    ref = ops._gather_raw(x, table)
+                finally:
+                    ops.USE_RESAMPLE_QUADS = True
+                assert rel(ops._gather_raw(x, table), ref.double()) < 5e-7, (t_in, p, q)
+                used += 1
+        T = T * up[i] // dn[i]
+    assert used >= 24
+
+
 @pytest.mark.parametrize("B", [4, 8, 32, 2])
 def test_minibatch_stddev_orders(dev, B):
     ops = _ops()
