@@ -15,6 +15,15 @@ inline unsigned blocks_for(size_t items) {
     return (unsigned)b;
 }
 
+// Grid of the 16-byte streaming kernels: a capped grid whose threads stride over the tensor is quickest
+// while the tensor lives in the caches (16 MB: 7.6 vs 8.2 us); from ~128 MB on one item per thread is, the
+// workgroups then sweep memory in address order (5.8 vs 5.1 TB/s).
+inline unsigned blocks_stream(size_t items) {
+    const size_t b = (items + 255) / 256;
+    if (b >= 32768 && b < ((size_t)1 << 31)) return (unsigned)b;
+    return blocks_for(items);
+}
+
 // ---- leaky-relu + drop backward ------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
@@ -311,7 +320,7 @@ extern "C" int eeggan_lrelu_drop_bwd(const float* g, const float* y, const float
     const size_t n = (size_t)B * C * T;
     const bool vec = (T % 4 == 0) && aligned16(g) && aligned16(y) && aligned16(out);
     if (vec)
-        hipLaunchKernelGGL(lrelu_drop_bwd_kernel<true>, dim3(blocks_for(n / 4)), dim3(256), 0, as_stream(stream), g, y,
+        hipLaunchKernelGGL(lrelu_drop_bwd_kernel<true>, dim3(blocks_stream(n / 4)), dim3(256), 0, as_stream(stream), g, y,
                            drop, out, n, T, slope);
     else
         hipLaunchKernelGGL(lrelu_drop_bwd_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), g, y,
@@ -375,7 +384,7 @@ extern "C" int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_
     EEGGAN_REQUIRE(gy && y && gc && n > 0, "tanh_bwd: null pointer or empty");
     const bool vec = (n % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
     if (vec)
-        hipLaunchKernelGGL(tanh_bwd_kernel<true>, dim3(blocks_for(n / 4)), dim3(256), 0, as_stream(stream), gy, y, gc,
+        hipLaunchKernelGGL(tanh_bwd_kernel<true>, dim3(blocks_stream(n / 4)), dim3(256), 0, as_stream(stream), gy, y, gc,
                            n, scale);
     else
         hipLaunchKernelGGL(tanh_bwd_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), gy, y, gc, n,
@@ -389,10 +398,10 @@ extern "C" int eeggan_axpby(const float* a, float ca, const float* b, float cb, 
     hipStream_t st = as_stream(stream);
     if (vec) {
         if (b)
-            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb, out,
+            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, ca, b, cb, out,
                                n, nullptr, 0);
         else
-            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, ca, b, cb,
+            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, ca, b, cb,
                                out, n, nullptr, 0);
     } else {
         if (b)
@@ -413,10 +422,10 @@ extern "C" int eeggan_blend(const float* a, const float* b, const float* alpha, 
     hipStream_t st = as_stream(stream);
     if (vec) {
         if (b)
-            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f, out,
+            hipLaunchKernelGGL((axpby_kernel<true, true>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f, out,
                                n, alpha, mode);
         else
-            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_for(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f,
+            hipLaunchKernelGGL((axpby_kernel<true, false>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f,
                                out, n, alpha, mode);
     } else {
         if (b)
