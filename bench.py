@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 DEPTH, ALPHA, BATCH = 7, 1.0, 32
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # 256 CUs x 4 SIMDs x 32*32*16*2 flop / 32 cycles x 2.4 GHz
 
 
 def parse():
@@ -122,10 +123,20 @@ def conv_roofline(dev, batch, T):
     # (2 x FETCH_SIZE + WRITE_SIZE = 2 x 11588.4 KiB + 15360 KiB; the algorithmic figure is 31.5 MB:
     # input + output once, weights, multipliers).  Only valid for the profiled shape.
     traffic = (2 * 11588.4375 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
-    return {"bound": "mfma", "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop)" % batch,
-            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "avg_launch_us": round(sec * 1e6, 2), "flop_per_launch": flops}
+    # The kernel forms every fp32 product from three bf16 pieces per operand (six bf16 MFMAs per 16
+    # reduction indices, fp32-exact to 2^-24): `achieved`/`frac` price the ALGORITHMIC fp32 flops against
+    # the fp32 matrix peak (the arithmetic type of the path); `pipe_frac` prices the six-fold executed
+    # work against the bf16 pipe it runs on.  EEGGAN_FP32_MFMA=1 selects the fp32 instructions instead.
+    fp32_mfma = os.environ.get("EEGGAN_FP32_MFMA") is not None
+    out = {"bound": "mfma", "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop)" % batch,
+           "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+           "avg_launch_us": round(sec * 1e6, 2), "flop_per_launch": flops,
+           "matrix_instruction": "v_mfma_f32_32x32x2_f32" if fp32_mfma else
+           "6 x v_mfma_f32_32x32x16_bf16 per 16 reduction indices (three bf16 pieces per fp32 operand)"}
+    if not fp32_mfma:
+        out["pipe_frac"] = round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)
+    return out
 
 
 def cpu_baseline(depth, alpha, batch, seed):

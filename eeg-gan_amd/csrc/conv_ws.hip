@@ -1,5 +1,8 @@
-// Weight-stationary fp32 MFMA convolution for the 64-channel layers of the path (k = 3, same
-// padding, at most 64 input and 64 output channels): forward and, on flipped weights, input gradient.
+// Weight-stationary MFMA convolution for the 64-channel layers of the path (k = 3, same padding, at
+// most 64 input and 64 output channels): forward and, on flipped weights, input gradient.  fp32 in,
+// fp32 out, fp32 accumulation; the 64 -> 64 layers form their products from three bf16 pieces per
+// operand on the bf16 matrix pipe (SPLIT below: fp32-exact to 2^-24, 2.7x fewer matrix cycles than
+// v_mfma_f32_32x32x2_f32), the ragged ones use the fp32 matrix instructions.
 //
 // These layers carry most of the step's flops but only ~10 us of matrix work per launch, so the
 // kernel is organised to keep the matrix pipes fed rather than around a workgroup-wide pipeline:
@@ -15,6 +18,7 @@
 //     channel) multiplier are applied on the way).
 #include "common.h"
 #include "conv_args.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace eeggan {
@@ -30,14 +34,35 @@ static_assert(64 * EL <= XREG, "output tile must fit the wave's region");
 
 __device__ __forceinline__ int xrow(int row) { return row * XL + (row >= 32 ? 32 : 0); }
 
+// SPLIT form: every fp32 operand is the sum of three bf16 pieces, v = p1 + p2 + p3 exactly up to 2^-24 |v|
+// (p1 = bf16(v), p2 = bf16(v - p1), p3 = bf16(v - p1 - p2); the differences are exact in fp32), and a product
+// of two such sums keeps the six terms down to 2^-16 of the leading one: p1q1 + p1q2 + p2q1 + p2q2 + p1q3 +
+// p3q1; the dropped terms are below 2^-24 of it, the rounding of an fp32 product.  Six bf16 MFMAs of 16
+// reduction indices (32 cycles each) replace eight fp32 MFMAs of 2 (64 cycles each).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WROWB = 400;           // bytes per output channel and piece: 8 groups x 3 taps x 8 channels x 2 B, + 16
+constexpr int WPLANE = 64 * WROWB;   // bytes per piece
+
+struct Split3 {
+    bf16x8 p1, p2, p3;
+};
+__device__ __forceinline__ void split3(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
 // K taps; MASKED: the input is multiplied by a saved LeakyReLU/GDrop mask while it is staged;
 // FULL: Cin == Cout == 64 and T % 32 == 0, so no load or store needs a predicate;
 // RM: 32-channel output tiles per unit.  RM = 2: a unit is a whole subtile (all 64 output channels).
 // RM = 1: a unit is one half of the output channels of a subtile (units 2s and 2s+1 share subtile s
 // and are taken by neighbouring waves): twice the input reads, but twice as many, half as long units,
 // which balances the four SIMDs of a CU when a layer has only a few subtiles per CU.
-template <int K, bool MASKED, bool FULL, int RM>
+template <int K, bool MASKED, bool FULL, int RM, bool SPLIT = false>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
+    static_assert(!SPLIT || (FULL && K == 3), "the split form covers the 64 -> 64, k = 3 layers");
     constexpr int PAD = (K - 1) / 2;
     constexpr int KK = 64 * K;   // reduction length with the input channels padded to 64
     constexpr int WLD = KK + 4;  // (WLD / 4) odd: conflict-free 16-byte row reads
@@ -51,7 +76,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     const int l31 = lane & 31;
     const int h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* Xs = smem + 64 * WLD + wave * XREG;
+    constexpr int WFLOATS = SPLIT ? 3 * WPLANE / 4 : 64 * WLD;  // weight region of the LDS image
+    float* Xs = smem + WFLOATS + wave * XREG;
 
     // staging coordinates of this lane: 16-byte items (row r0 + 8 i, floats 4q..4q+3) and halo items
     const int q = lane & 7, r0 = lane >> 3;
@@ -185,6 +211,22 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             f32x4 v = wv[FULL ? i : 0];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
+            if (SPLIT) {
+                // piece planes, [co][lane half h][chunk c][tap][8 channels]: the 8 channels 32h + 8c + i of one
+                // tap are one 16-byte operand fragment
+                char* Wb = reinterpret_cast<char*>(smem);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q4 + e, ci = k / 3, tap = k - 3 * ci;
+                    const int off = co * WROWB + ((((ci >> 5) * 4 + ((ci & 31) >> 3)) * 3 + tap) * 8 + (ci & 7)) * 2;
+                    __bf16 p1, p2, p3;
+                    split3(v[e], p1, p2, p3);
+                    *reinterpret_cast<__bf16*>(Wb + off) = p1;
+                    *reinterpret_cast<__bf16*>(Wb + WPLANE + off) = p2;
+                    *reinterpret_cast<__bf16*>(Wb + 2 * WPLANE + off) = p3;
+                }
+                continue;
+            }
             *reinterpret_cast<f32x4*>(Ws + co * WLD + 4 * q4) = v;
         }
     } else {
@@ -242,6 +284,37 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             commit_chunk(cur, c);
             if (MORE) issue_chunk(nxt, c);
             __builtin_amdgcn_sched_barrier(0);
+            if (SPLIT) {
+                const char* Wb = reinterpret_cast<const char*>(smem) + (co_base + l31) * WROWB + (h * 4 + c) * 3 * 16;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    bf16x8 x1, x2, x3;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __bf16 p1, p2, p3;
+                        split3(Bp[(8 * c + i) * XL + j], p1, p2, p3);
+                        x1[i] = p1;
+                        x2[i] = p2;
+                        x3[i] = p3;
+                    }
+#pragma unroll
+                    for (int tile = 0; tile < RM; ++tile) {
+                        const char* wp = Wb + tile * 32 * WROWB + j * 16;
+                        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp);
+                        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + WPLANE);
+                        const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(wp + 2 * WPLANE);
+                        f32x16& acc = tile == 0 ? acc0 : acc1;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w3, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w2, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1, acc, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int s4 = c * (2 * K); s4 < (c + 1) * (2 * K); ++s4) {
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(Au + 4 * s4);
@@ -371,10 +444,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     unit_body(std::false_type{}, cur);
 }
 
-template <int K, bool MASKED, bool FULL, int RM>
+template <int K, bool MASKED, bool FULL, int RM, bool SPLIT = false>
 int launch(const ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)(64 * (64 * K + 4) + WS_WAVES * XREG) * sizeof(float);
-    auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM>;
+    constexpr size_t lds = (size_t)((SPLIT ? 3 * WPLANE / 4 : 64 * (64 * K + 4)) + WS_WAVES * XREG) * sizeof(float);
+    auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM, SPLIT>;
     static bool ready = false;  // opt in to > 64 KiB of dynamic LDS (once)
     if (!ready) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -404,6 +477,11 @@ int launch_rm(const ConvArgs& a, hipStream_t st) {
     const long long waves = 8ll * num_cus();
     const long long whole = (a.NS + waves - 1) / waves * 2, half = (2ll * a.NS + waves - 1) / waves;
     const bool halves = a.act != ACT_LRELU_PN && (a.NS < waves || half < whole);  // (the norm needs all channels in one unit)
+    if constexpr (FULL && K == 3) {
+        // (EEGGAN_FP32_MFMA=1 in the environment keeps the fp32 matrix instructions: comparison runs)
+        static const bool split = getenv("EEGGAN_FP32_MFMA") == nullptr;
+        if (split) return halves ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
+    }
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
 

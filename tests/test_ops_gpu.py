@@ -133,6 +133,30 @@ def test_conv_thin_large_batch(dev, Cin, Cout):
     assert rel(y[sel], refm) < TOL
 
 
+def test_conv_split_products_are_fp32_exact(dev):
+    """The 64 -> 64, k = 3 layers multiply on the bf16 matrix pipe, every fp32 operand as the sum of three
+    bf16 pieces and six of the nine piece products kept.  Against fp64 the result must be as good as an
+    fp32 computation: held here to 5e-7 norm-wise and 2e-6 of the largest output element-wise, on inputs
+    with a wide dynamic range (so that the low pieces matter) -- a plain bf16 product would sit at 3e-3,
+    two pieces per operand at 1e-5."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, T = 16, 1024
+    x = torch.randn(B, 64, T, generator=g) * torch.exp(2.0 * torch.randn(B, 64, 1, generator=g))
+    w = torch.randn(64, 64, 3, generator=g) * torch.exp(torch.randn(64, 64, 1, generator=g))
+    b = torch.randn(64, generator=g)
+    y = ops.conv1d_raw(x.to(dev), w.to(dev), b.to(dev), None, in_scale=0.37)
+    ref = conv_ref(x, w, b, 0.37, 1)
+    assert rel(y, ref) < 5e-7
+    assert float((y.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # the input gradient takes the same kernel on the flipped weights
+    gy = torch.randn(B, 64, T, generator=g)
+    x64 = x.double().requires_grad_(True)
+    (gx_ref,) = torch.autograd.grad(F.conv1d(x64 * 0.37, w.double(), None, padding=1), x64, gy.double())
+    gx = ops.conv1d_raw(gy.to(dev), w.to(dev), None, None, in_scale=0.37, transposed=True)
+    assert rel(gx, gx_ref) < 5e-7
+
+
 def test_conv_wgrad_deterministic(dev):
     ops = _ops()
     x = torch.randn(8, 64, 768, device=dev)
