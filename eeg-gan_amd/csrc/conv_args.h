@@ -53,6 +53,7 @@ constexpr int ACT_LRELU_PN = 4;
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st);
 bool conv_ws_covers(const ConvArgs& a, int K);
 int num_cus();
+bool split_products();
 // Bandwidth-bound form for 1x1 convs with at most 8 input or output channels (conv_thin.hip); -1 when
 // the shape is not covered.
 int launch_conv_thin(const ConvArgs& a, int K, hipStream_t st);

@@ -611,6 +611,13 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
 
 }  // namespace
 
+// fp32 products from three bf16 pieces on the bf16 matrix pipe (default) or the fp32 matrix instructions
+// (EEGGAN_FP32_MFMA=1 in the environment: comparison runs)
+bool split_products() {
+    static const bool on = getenv("EEGGAN_FP32_MFMA") == nullptr;
+    return on;
+}
+
 int num_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -720,6 +727,15 @@ __global__ __launch_bounds__(256) void flip_weights_multi_kernel(FlipPack pk) {
 // ---------------------------------------------------------------------------------------
 // Weight gradient.  A workgroup owns a 64(co) x 64(ci) x K region of gw and a contiguous
 // range of subtile pairs; wave w accumulates the 32x32xK tile (co half = w>>1, ci half = w&1).
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3s(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
 struct WgradArgs {
     const float* x;
     const float* gy;
@@ -738,8 +754,12 @@ struct WgradArgs {
 // FULL: Cin % 64 == 0, Cout % 64 == 0, T % 32 == 0 and T % 4 == 0: staging without predicates on
 // channels or time, with one wave-uniform (sample, time) decode per iteration, two LDS buffers and a
 // single barrier per iteration.  Otherwise the generic XStage path.
-template <int K, bool FULL>
+// SPLIT (FULL, K = 3): the products run on the bf16 matrix pipe, each fp32 operand as the sum of three bf16
+// pieces with the six leading piece products kept (fp32-exact to 2^-24; see conv_ws.hip): 18 MFMAs of 16
+// time steps replace 24 fp32 MFMAs of 2.
+template <int K, bool FULL, bool SPLIT = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
+    static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
     constexpr int PAD = (K - 1) / 2;
     constexpr int NTW = 2;
     constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
@@ -769,6 +789,53 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     if (it1 > total_pairs) it1 = total_pairs;
 
     auto mfma_block = [&](const float* Gs, const float* Xs) {
+        if constexpr (SPLIT) {
+            const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h;
+            const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+#pragma unroll
+                for (int tb = 0; tb < 32; tb += 16) {
+                    // this lane's 8 time steps tb + 8h .. +7 of the gradient row, and the 10 input samples around them
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + n * SUB + tb);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(Gr + n * SUB + tb + 4);
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Xr + n * SUB + tb);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Xr + n * SUB + tb + 4);
+                    const float xs[10] = {Xr[n * SUB + tb - 1], x0[0], x0[1], x0[2], x0[3],
+                                          x1[0], x1[1], x1[2], x1[3], Xr[n * SUB + tb + 8]};
+                    if (do_bias) bsum += ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]));
+                    bf16x8s G1, G2, G3;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __bf16 p1, p2, p3;
+                        split3s(i < 4 ? g0[i] : g1[i - 4], p1, p2, p3);
+                        G1[i] = p1;
+                        G2[i] = p2;
+                        G3[i] = p3;
+                    }
+                    __bf16 q1[10], q2[10], q3[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) split3s(xs[i], q1[i], q2[i], q3[i]);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        bf16x8s X1, X2, X3;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            X1[i] = q1[i + j];
+                            X2[i] = q2[i + j];
+                            X3[i] = q3[i + j];
+                        }
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G3, X1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X3, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G2, X2, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G2, X1, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X2, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X1, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
         const float* Gp = Gs + (cot * 32 + l31) * LD + 4 + 4 * h;
         const float* Xp = Xs + (cit * 32 + l31) * LD + 4 + 4 * h;
 #pragma unroll
@@ -916,9 +983,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     }
 }
 
-template <int K, bool FULL>
+template <int K, bool FULL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-    wgrad_body<K, FULL>(a, blockIdx.x, blockIdx.y);
+    wgrad_body<K, FULL, SPLIT>(a, blockIdx.x, blockIdx.y);
 }
 
 // Several independent weight gradients in one launch: the workgroups of the grid are dealt out to the
@@ -932,7 +999,7 @@ struct WgradPack {
     int n;
 };
 
-template <int K, bool FULL>
+template <int K, bool FULL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
@@ -940,7 +1007,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradPack pk) {
     const WgradArgs a = pk.j[k];
     const int local = blk - pk.first[k];
     const int region = local / a.nsplit;
-    wgrad_body<K, FULL>(a, local - region * a.nsplit, region);
+    wgrad_body<K, FULL, SPLIT>(a, local - region * a.nsplit, region);
 }
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
@@ -1136,10 +1203,16 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
         if (!ready) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
             EEGGAN_REQUIRE(e == hipSuccess, "%s: cannot reserve LDS: %s", what, hipGetErrorString(e));
             ready = true;
         }
-        hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
+        if (split_products())
+            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, true>), grid, dim3(256), 2 * lds1, st, a);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
     } else if (K == 3) {
         hipLaunchKernelGGL((conv_wgrad_kernel<3, false>), grid, dim3(256), lds1, st, a);
     } else {
@@ -1322,11 +1395,17 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 if (!ready) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                    if (e == hipSuccess)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad_partial_multi: cannot reserve LDS: %s",
                                    hipGetErrorString(e));
                     ready = true;
                 }
-                hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
+                if (split_products())
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
+                else
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
             } else if (v == 1) {
                 hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, false>), dim3(first), dim3(256), lds1, st, pk);
             } else {

@@ -479,8 +479,7 @@ int launch_rm(const ConvArgs& a, hipStream_t st) {
     const bool halves = a.act != ACT_LRELU_PN && (a.NS < waves || half < whole);  // (the norm needs all channels in one unit)
     if constexpr (FULL && K == 3) {
         // (EEGGAN_FP32_MFMA=1 in the environment keeps the fp32 matrix instructions: comparison runs)
-        static const bool split = getenv("EEGGAN_FP32_MFMA") == nullptr;
-        if (split) return halves ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
+        if (split_products()) return halves ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
     }
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }

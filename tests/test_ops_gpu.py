@@ -155,6 +155,12 @@ def test_conv_split_products_are_fp32_exact(dev):
     (gx_ref,) = torch.autograd.grad(F.conv1d(x64 * 0.37, w.double(), None, padding=1), x64, gy.double())
     gx = ops.conv1d_raw(gy.to(dev), w.to(dev), None, None, in_scale=0.37, transposed=True)
     assert rel(gx, gx_ref) < 5e-7
+    # the weight gradient of every predicate-free k = 3 layer splits its operands the same way
+    w64 = w.double().requires_grad_(True)
+    (gw_ref,) = torch.autograd.grad(F.conv1d(x.double(), w64 * 0.37, None, padding=1), w64, gy.double())
+    gw, gb = ops.conv1d_wgrad_raw(x.to(dev), gy.to(dev), 3, in_scale=0.37)
+    assert rel(gw, gw_ref) < 5e-7
+    assert rel(gb, gy.double().sum((0, 2))) < 5e-7
 
 
 def test_conv_wgrad_deterministic(dev):
