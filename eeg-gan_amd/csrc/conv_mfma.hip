@@ -26,6 +26,16 @@ namespace {
 
 constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment)
 
+// Split products: an fp32 operand as the sum of three bf16 pieces (v = p1 + p2 + p3 up to 2^-24 |v|), see conv_ws.hip
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3s(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)v;
+    const float r1 = v - (float)p1;
+    p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    p3 = (__bf16)r2;
+}
+
 // ---------------------------------------------------------------------------------------
 // Global -> register -> LDS staging of ROWS channels x NT subtiles of an activation.
 template <int ROWS, int NT, int LD, bool HALO>
@@ -144,10 +154,17 @@ struct XStage {
 //   plus wave-uniform chunk offsets);  KS (1|2): the waves split each chunk's reduction indices KS
 //   ways and sum their accumulators through LDS before the epilogue -- for layers with so few
 //   (b, t) positions (T = 32) that the tile has to be one subtile wide to give every CU work.
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, int NTHR = 64 * WM * WN * KS>
+//   SPLIT (FULL, K = 3, CK = 32): products on the bf16 matrix pipe from three bf16 pieces per operand (six piece
+//   products, fp32-exact to 2^-24).  The weight chunk is split once, when it is staged: three piece planes
+//   [CT][k-step s = 2 tap + (ci >> 4)][lane half (ci >> 3) & 1][8 channels], one 16-byte operand fragment per
+//   (row, k-step, lane half), rows WROWB bytes apart; the activations stay fp32 in LDS and are split as read.
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, bool SPLIT = false,
+          int NTHR = 64 * WM * WN * KS>
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
+    static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
     constexpr int PAD = (K - 1) / 2;
-    constexpr int WLD = CK * K + 4;  // LDS row stride of the weight chunk (conflict-free b128 reads)
+    constexpr int WROWB = CK * K * 2 + 16;  // SPLIT: bytes per weight row and piece (conflict-free b128 reads)
+    constexpr int WLD = SPLIT ? 3 * WROWB / 4 : CK * K + 4;  // LDS floats per weight row of a chunk (fp32 form: conflict-free b128 reads)
     constexpr int XLD = NT * SUB;
     constexpr int RM = CT / 32 / WM;
     constexpr int RN = NT / WN;
@@ -371,7 +388,21 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 f32x4 v = wv[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
-                *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
+                if constexpr (SPLIT) {
+                    char* Wb = reinterpret_cast<char*>(Ws) + w_row[i] * WROWB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * w_q[i] + e, ci = k / 3, tap = k - 3 * ci;
+                        const int off = ((tap * 2 + (ci >> 4)) * 2 + ((ci >> 3) & 1)) * 16 + (ci & 7) * 2;
+                        __bf16 p1, p2, p3;
+                        split3s(v[e], p1, p2, p3);
+                        *reinterpret_cast<__bf16*>(Wb + off) = p1;
+                        *reinterpret_cast<__bf16*>(Wb + CT * WROWB + off) = p2;
+                        *reinterpret_cast<__bf16*>(Wb + 2 * CT * WROWB + off) = p3;
+                    }
+                } else {
+                    *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
+                }
             }
 #pragma unroll
             for (int i = 0; i < XV; ++i) {
@@ -466,6 +497,44 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         const float* buf = smem + (step & 1) * BUF;
         const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
         const float* Bp = buf + CT * WLD + h * (CK / 2) * XLD + wn * RN * SUB + (4 - PAD) + l31;
+        if constexpr (SPLIT) {
+            // k-step s = (tap j, channel half g): this lane's 8 channels are 16 g + 8 h + i, at time l31 + j - 1
+            const char* Wb = reinterpret_cast<const char*>(buf) + (wm * RM * 32 + l31) * WROWB + h * 16;
+            const float* Bq = buf + CT * WLD + h * 8 * XLD + wn * RN * SUB + (4 - PAD) + l31;
+#pragma unroll
+            for (int s = kid * (6 / KS); s < (kid + 1) * (6 / KS); ++s) {
+                const int j = s >> 1, g = s & 1;
+                bf16x8s w1[RM], w2[RM], w3[RM];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) {
+                    const char* wp = Wb + i * 32 * WROWB + s * 32;
+                    w1[i] = *reinterpret_cast<const bf16x8s*>(wp);
+                    w2[i] = *reinterpret_cast<const bf16x8s*>(wp + CT * WROWB);
+                    w3[i] = *reinterpret_cast<const bf16x8s*>(wp + 2 * CT * WROWB);
+                }
+#pragma unroll
+                for (int n = 0; n < RN; ++n) {
+                    bf16x8s x1, x2, x3;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __bf16 p1, p2, p3;
+                        split3s(Bq[(16 * g + i) * XLD + n * SUB + j], p1, p2, p3);
+                        x1[i] = p1;
+                        x2[i] = p2;
+                        x3[i] = p3;
+                    }
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w3[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w2[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w2[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i], acc[i][n], 0, 0, 0);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int s4 = kid * (KH / 4 / KS); s4 < (kid + 1) * (KH / 4 / KS); ++s4) {
             f32x4 av[RM];
@@ -631,10 +700,11 @@ int num_cus() {
 
 namespace {
 
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, bool SPLIT = false>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
-    constexpr size_t lds = ((size_t)2 * (CT * (CK * K + 4) + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
-    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS>;
+    constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
+    constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT>;
     static int per_cu = 0;  // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once)
     if (per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -677,7 +747,15 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     // one-subtile tiles): batches that are not a multiple of the chip width lose up to half a round on the big tile.
     const long long cus = num_cus();
     const long long cost4 = (tiles(64, 4) + cus - 1) / cus * 4 * 20, cost1 = (tiles(64, 1) + 2 * cus - 1) / (2 * cus) * 2 * 21;
-    if (tiles(64, 4) >= cus && cost4 <= cost1)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
+    const bool big = tiles(64, 4) >= cus && cost4 <= cost1;
+    if constexpr (K == 3) {
+        // predicate-free layers: products from bf16 pieces.  The narrow tile is 32 channels x 2 subtiles there (as many
+        // tiles as 64 x 1): with the weight chunk as three piece planes that is what still fits twice on a CU.
+        if (full && split_products())
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true>(a, st);
+    }
+    if (big)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
         return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
     return full ? launch_fwd<K, 64, 1, 32, 2, 1, true, true, 2>(a, st) : launch_fwd<K, 64, 1, 32, 2, 1, true, false, 2>(a, st);
 }
@@ -727,15 +805,6 @@ __global__ __launch_bounds__(256) void flip_weights_multi_kernel(FlipPack pk) {
 // ---------------------------------------------------------------------------------------
 // Weight gradient.  A workgroup owns a 64(co) x 64(ci) x K region of gw and a contiguous
 // range of subtile pairs; wave w accumulates the 32x32xK tile (co half = w>>1, ci half = w&1).
-typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3s(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
-    p1 = (__bf16)v;
-    const float r1 = v - (float)p1;
-    p2 = (__bf16)r1;
-    const float r2 = r1 - (float)p2;
-    p3 = (__bf16)r2;
-}
-
 struct WgradArgs {
     const float* x;
     const float* gy;

@@ -161,6 +161,15 @@ def test_conv_split_products_are_fp32_exact(dev):
     gw, gb = ops.conv1d_wgrad_raw(x.to(dev), gy.to(dev), 3, in_scale=0.37)
     assert rel(gw, gw_ref) < 5e-7
     assert rel(gb, gy.double().sum((0, 2))) < 5e-7
+    # the wider predicate-free layers (tiled kernel): the eight-wave tile and the narrow tile of the short layers
+    for B2, C, T2 in ((64, 128, 512), (8, 256, 32), (3, 128, 96)):
+        x = torch.randn(B2, C, T2, generator=g) * torch.exp(2.0 * torch.randn(B2, C, 1, generator=g))
+        w = torch.randn(C, C, 3, generator=g) * torch.exp(torch.randn(C, C, 1, generator=g))
+        b = torch.randn(C, generator=g)
+        y = ops.conv1d_raw(x.to(dev), w.to(dev), b.to(dev), None, in_scale=0.21)
+        ref = conv_ref(x, w, b, 0.21, 1)
+        assert rel(y, ref) < 5e-7, (B2, C, T2)
+        assert float((y.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6, (B2, C, T2)
 
 
 def test_conv_wgrad_deterministic(dev):
