@@ -185,7 +185,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     constexpr int Q4 = KK / 4;
     constexpr int WV = 64 * Q4 / 512;
     f32x4 wv[FULL ? WV : 1];
-    if (FULL) {
+    if (SPLIT) {
+        // thread = (output channel tid >> 3, group of 8 input channels tid & 7): 24 consecutive floats, which
+        // become one 16-byte fragment per tap and piece
+        static_assert(!SPLIT || WV == 6, "one (row, 8-channel group) per thread");
+#pragma unroll
+        for (int i = 0; i < WV; ++i) wv[FULL ? i : 0] = *reinterpret_cast<const f32x4*>(a.w + (long long)tid * 24 + 4 * i);
+    } else if (FULL) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int e4 = tid + 512 * i;
@@ -203,7 +209,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     for (int c = 0; c < 4; ++c) issue_chunk(cur, c);
     __builtin_amdgcn_sched_barrier(0);
     EEGGAN_STAMP(15, 1);
-    if (FULL) {
+    if (SPLIT) {
+        // piece planes, [co][lane half h][chunk c][tap][8 channels]: the 8 channels 32h + 8c + i of one tap are one
+        // 16-byte operand fragment; this thread's group is (h, c) = (group >> 2, group & 3), i.e. slot `group`
+        char* Wb = reinterpret_cast<char*>(smem) + (tid >> 3) * WROWB + (tid & 7) * 3 * 16;
+        bf16x8 p[3][3];  // [tap][piece]
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * i + e, ci = k / 3, tap = k - 3 * ci;  // this thread's float k: channel ci of its group
+                __bf16 p1, p2, p3;
+                split3(wv[FULL ? i : 0][e] * a.in_scale, p1, p2, p3);
+                p[tap][0][ci] = p1;
+                p[tap][1][ci] = p2;
+                p[tap][2][ci] = p3;
+            }
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(Wb + k * WPLANE + tap * 16) = p[tap][k];
+    } else if (FULL) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int e4 = tid + 512 * i;
@@ -211,22 +237,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             f32x4 v = wv[FULL ? i : 0];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
-            if (SPLIT) {
-                // piece planes, [co][lane half h][chunk c][tap][8 channels]: the 8 channels 32h + 8c + i of one
-                // tap are one 16-byte operand fragment
-                char* Wb = reinterpret_cast<char*>(smem);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = 4 * q4 + e, ci = k / 3, tap = k - 3 * ci;
-                    const int off = co * WROWB + ((((ci >> 5) * 4 + ((ci & 31) >> 3)) * 3 + tap) * 8 + (ci & 7)) * 2;
-                    __bf16 p1, p2, p3;
-                    split3(v[e], p1, p2, p3);
-                    *reinterpret_cast<__bf16*>(Wb + off) = p1;
-                    *reinterpret_cast<__bf16*>(Wb + WPLANE + off) = p2;
-                    *reinterpret_cast<__bf16*>(Wb + 2 * WPLANE + off) = p3;
-                }
-                continue;
-            }
             *reinterpret_cast<f32x4*>(Ws + co * WLD + 4 * q4) = v;
         }
     } else {
