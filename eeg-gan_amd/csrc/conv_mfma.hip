@@ -28,6 +28,7 @@ constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment
 
 // Split products: an fp32 operand as the sum of three bf16 pieces (v = p1 + p2 + p3 up to 2^-24 |v|), see conv_ws.hip
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3s(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)v;
     const float r1 = v - (float)p1;
@@ -203,9 +204,15 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     int w_row[WV], w_q[WV];
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-        const int e4 = tid + NTHR * i;
-        w_row[i] = e4 / WQ;
-        w_q[i] = e4 - w_row[i] * WQ;
+        if (SPLIT) {  // a thread owns 4 consecutive channels of one weight row: 12 floats, one 8-byte fragment half per tap and piece
+            static_assert(!SPLIT || (WV == 3 && NTHR == CT * 8), "one (row, 4-channel group) per thread");
+            w_row[i] = tid >> 3;
+            w_q[i] = (tid & 7) * 3 + i;
+        } else {
+            const int e4 = tid + NTHR * i;
+            w_row[i] = e4 / WQ;
+            w_q[i] = e4 - w_row[i] * WQ;
+        }
     }
     const int x_q = tid & 7, x_n = (tid >> 3) % NT, x_row0 = (tid >> 3) / NT;
     const int h_side = tid & 1, h_n = (tid >> 1) % NT, h_row0 = (tid >> 1) / NT;
@@ -383,24 +390,32 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         float* Ws = buf;
         float* Xs = buf + CT * WLD;
         if (FULL) {
+            if constexpr (SPLIT) {
+                bf16x4s p[3][3];  // [tap][piece]: this thread's channels 4 (tid & 7) .. + 3 of the chunk
 #pragma unroll
-            for (int i = 0; i < WV; ++i) {
-                f32x4 v = wv[i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
-                if constexpr (SPLIT) {
-                    char* Wb = reinterpret_cast<char*>(Ws) + w_row[i] * WROWB;
+                for (int i = 0; i < WV; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int k = 4 * w_q[i] + e, ci = k / 3, tap = k - 3 * ci;
-                        const int off = ((tap * 2 + (ci >> 4)) * 2 + ((ci >> 3) & 1)) * 16 + (ci & 7) * 2;
+                        const int k = 4 * i + e, c = k / 3, tap = k - 3 * c;
                         __bf16 p1, p2, p3;
-                        split3s(v[e], p1, p2, p3);
-                        *reinterpret_cast<__bf16*>(Wb + off) = p1;
-                        *reinterpret_cast<__bf16*>(Wb + CT * WROWB + off) = p2;
-                        *reinterpret_cast<__bf16*>(Wb + 2 * CT * WROWB + off) = p3;
+                        split3s(wv[i][e] * a.in_scale, p1, p2, p3);
+                        p[tap][0][c] = p1;
+                        p[tap][1][c] = p2;
+                        p[tap][2][c] = p3;
                     }
-                } else {
+                const int g4 = tid & 7;  // channels 4 g4 ..: k-step half g4 >> 2, lane half (g4 >> 1) & 1, fragment half g4 & 1
+                char* Wb = reinterpret_cast<char*>(Ws) + (tid >> 3) * WROWB + (g4 >> 2) * 32 + ((g4 >> 1) & 1) * 16 + (g4 & 1) * 8;
+#pragma unroll
+                for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        *reinterpret_cast<bf16x4s*>(Wb + k * CT * WROWB + tap * 64) = p[tap][k];
+            } else {
+#pragma unroll
+                for (int i = 0; i < WV; ++i) {
+                    f32x4 v = wv[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= a.in_scale;
                     *reinterpret_cast<f32x4*>(Ws + w_row[i] * WLD + 4 * w_q[i]) = v;
                 }
             }
