@@ -159,7 +159,10 @@ struct XStage {
 //   products, fp32-exact to 2^-24).  The weight chunk is split once, when it is staged: three piece planes
 //   [CT][k-step s = 2 tap + (ci >> 4)][lane half (ci >> 3) & 1][8 channels], one 16-byte operand fragment per
 //   (row, k-step, lane half), rows WROWB bytes apart; the activations stay fp32 in LDS and are split as read.
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, bool SPLIT = false,
+//   MASK (-1 | 0 | 1): whether the input carries a fused backward mask; -1 decides at run time.  The two-stage
+//   prefetch wants it known at compile time: a branch around the mask loads makes the load counts the waits
+//   are computed from path-dependent, and the waits conservative.
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, bool SPLIT = false, int MASK = -1,
           int NTHR = 64 * WM * WN * KS>
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     const int nsteps = my_tiles * nchunks;
     if (nsteps <= 0) return;
     const bool wvec = ((a.Cin * K) % 4 == 0) && (a.Cin % CK == 0);
+    const bool has_mask = MASK < 0 ? a.mask_y != nullptr : MASK != 0;
 
     // per-thread staging coordinates that do not depend on the step
     int w_row[WV], w_q[WV];
@@ -217,8 +221,19 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     const int x_q = tid & 7, x_n = (tid >> 3) % NT, x_row0 = (tid >> 3) / NT;
     const int h_side = tid & 1, h_n = (tid >> 1) % NT, h_row0 = (tid >> 1) / NT;
 
-    f32x4 wv[WV], xv[XV];
-    float hv[HV];
+    // Registers of one prefetched step.  SPLIT keeps two steps in flight (DEEP): the loads of step s + 2 are issued
+    // before the MFMAs of step s and written to LDS after the MFMAs of step s + 1, so they have a whole step to
+    // arrive -- a chunk's MFMAs are shorter than a trip to L2 once the products run on the bf16 pipe.
+    constexpr bool DEEP = SPLIT;
+    struct Stage {
+        f32x4 wv[WV], xv[XV];
+        f32x4 mv[VEC ? XV : 1];  // mask_y values of the activation items (VEC path)
+        float hv[HV], mdv[XV], mhv[HV], mdh[HV];
+        unsigned okbits;         // bit i: weight item i valid; bit 8+i: activation item i; bit 16+i: halo i
+        int p_lim;
+        bool x_ok, h_ok;         // the tile-level validity of this thread's items when the step was prefetched
+    };
+    Stage sa, sb;
 
     // state of the step being prefetched
     int p_tile = blockIdx.x, p_chunk = 0;
@@ -237,6 +252,10 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     const float* fdh = a.x;
 
     auto setup_tile = [&](int tile) {
+        // (a tile past the end -- the two-stage prefetch runs unconditionally -- stages nothing: all of its loads
+        // go to one fixed address)
+        const bool live = tile < ntiles;
+        if (!live) tile = 0;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         p_co0 = ty * CT;
         const int sub0 = tx * NT;
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const int sub = sub0 + x_n;
             const int b = sub / a.ST;
             const int t = (sub - b * a.ST) * 32 + 4 * x_q;
-            x_ok = sub < a.NS && t < a.T;
+            x_ok = live && sub < a.NS && t < a.T;
             x_b = b;
             x_off = ((long long)b * a.Cin + x_row0) * a.T + t;
         }
@@ -253,18 +272,16 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const int b = sub / a.ST;
             const int t = (sub - b * a.ST) * 32 + (h_side ? 32 : -1);
             // (with few subtiles per tile the halo pass has more threads than the chunk has rows)
-            h_ok = sub < a.NS && t >= 0 && t < a.T && h_row0 < CK;
+            h_ok = live && sub < a.NS && t >= 0 && t < a.T && h_row0 < CK;
             h_b = b;
             h_off = ((long long)b * a.Cin + h_row0) * a.T + t;
         }
         if (FULL) {
 #pragma unroll
-            for (int i = 0; i < WV; ++i) fw[i] = a.w + ((long long)(p_co0 + w_row[i]) * a.Cin) * K + 4 * w_q[i];
-            x_ok = x_ok && tile < ntiles;
-            h_ok = h_ok && tile < ntiles;
+            for (int i = 0; i < WV; ++i) fw[i] = live ? a.w + ((long long)(p_co0 + w_row[i]) * a.Cin) * K + 4 * w_q[i] : a.w;
             fx = a.x + (x_ok ? x_off : 0);
             fh = a.x + (h_ok ? h_off : 0);
-            if (a.mask_y) {
+            if (has_mask) {
                 fmx = a.mask_y + (x_ok ? x_off : 0);
                 fmh = a.mask_y + (h_ok ? h_off : 0);
                 if (a.mask_drop) {
@@ -280,12 +297,18 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     // the equalized-lr scale) runs in commit(), after the MFMA block, so the loads' latency hides
     // under it.  A predicated load, or a select right behind the load, makes the compiler wait for
     // the whole prefetch before the first MFMA.
-    f32x4 mv[VEC ? XV : 1];   // mask_y values of the activation items (VEC path)
-    float mdv[XV], mhv[HV], mdh[HV];
-    unsigned okbits = 0;      // bit i: weight item i valid; bit 8+i: activation item i; bit 16+i: halo i
-    int p_lim = 0;
-
-    auto prefetch = [&]() {  // global -> registers for step (p_tile, p_chunk)
+    auto prefetch = [&](Stage& s) {  // global -> registers for step (p_tile, p_chunk)
+        auto& wv = s.wv;
+        auto& xv = s.xv;
+        auto& mv = s.mv;
+        auto& hv = s.hv;
+        auto& mdv = s.mdv;
+        auto& mhv = s.mhv;
+        auto& mdh = s.mdh;
+        unsigned& okbits = s.okbits;
+        int& p_lim = s.p_lim;
+        s.x_ok = x_ok;
+        s.h_ok = h_ok;
         const int ci0 = p_chunk * CK;
         if (FULL) {
             // every address = per-tile base + a wave-uniform offset; a whole-item predicate (tile tail,
@@ -298,9 +321,9 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             for (int i = 0; i < XV; ++i) {
                 const long long o = x_ok ? xo + (long long)(i * XROWS) * a.T : 0;
                 xv[i] = *reinterpret_cast<const f32x4*>(fx + o);
-                if (a.mask_y) {  // wave-uniform
+                if (has_mask) {  // wave-uniform
                     mv[VEC ? i : 0] = *reinterpret_cast<const f32x4*>(fmx + o);
-                    mdv[i] = a.mask_drop ? fdx[x_ok ? ci0 + i * XROWS : 0] : 1.f;
+                    mdv[i] = fdx[(x_ok && a.mask_drop) ? ci0 + i * XROWS : 0];  // (without multipliers: any valid address; selected in commit)
                 }
             }
             if (K > 1) {
@@ -309,9 +332,9 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                     const bool ok = h_ok && h_row0 + i * HROWS < CK;
                     const long long o = ok ? xo + (long long)(i * HROWS) * a.T : 0;
                     hv[i] = fh[o];
-                    if (a.mask_y) {
+                    if (has_mask) {
                         mhv[i] = fmh[o];
-                        mdh[i] = a.mask_drop ? fdh[ok ? ci0 + i * HROWS : 0] : 1.f;
+                        mdh[i] = fdh[(ok && a.mask_drop) ? ci0 + i * HROWS : 0];
                     }
                 }
             }
@@ -352,19 +375,19 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             if (VEC) {
                 const long long o = ok ? off : 0;
                 xv[i] = *reinterpret_cast<const f32x4*>(a.x + o);
-                if (a.mask_y) {  // wave-uniform
+                if (has_mask) {  // wave-uniform
                     mv[VEC ? i : 0] = *reinterpret_cast<const f32x4*>(a.mask_y + o);
                     mdv[i] = a.mask_drop ? a.mask_drop[ok ? x_b * a.Cin + c : 0] : 1.f;
                 }
             } else {
                 const int t = (int)((x_off - ((long long)x_b * a.Cin + x_row0) * a.T));
-                const float md = (a.mask_y && a.mask_drop) ? a.mask_drop[ok ? x_b * a.Cin + c : 0] : 1.f;
+                const float md = (has_mask && a.mask_drop) ? a.mask_drop[ok ? x_b * a.Cin + c : 0] : 1.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool oke = ok && t + e < a.T;
                     const long long o = oke ? off + e : 0;
                     float u = a.x[o];
-                    if (a.mask_y) u *= a.mask_y[o] > 0.f ? md : md * a.mask_slope;
+                    if (has_mask) u *= a.mask_y[o] > 0.f ? md : md * a.mask_slope;
                     xv[i][e] = oke ? u : 0.f;  // (rare path: T % 4 != 0)
                 }
             }
@@ -378,7 +401,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 okbits |= ok ? (1u << (16 + i)) : 0u;
                 const long long off = ok ? h_off + coff + (long long)(i * HROWS) * a.T : 0;
                 hv[i] = a.x[off];
-                if (a.mask_y) {
+                if (has_mask) {
                     mhv[i] = a.mask_y[off];
                     mdh[i] = a.mask_drop ? a.mask_drop[ok ? h_b * a.Cin + c : 0] : 1.f;
                 }
@@ -386,7 +409,17 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         }
     };
 
-    auto commit = [&](float* buf) {  // registers -> LDS buffer (all consumers of the prefetch live here)
+    auto commit = [&](const Stage& s, float* buf) {  // registers -> LDS buffer (all consumers of the prefetch live here)
+        const auto& wv = s.wv;
+        const auto& xv = s.xv;
+        const auto& mv = s.mv;
+        const auto& hv = s.hv;
+        const auto& mdv = s.mdv;
+        const auto& mhv = s.mhv;
+        const auto& mdh = s.mdh;
+        const unsigned okbits = s.okbits;
+        const int p_lim = s.p_lim;
+        const bool x_ok = s.x_ok, h_ok = s.h_ok;
         float* Ws = buf;
         float* Xs = buf + CT * WLD;
         if (FULL) {
@@ -422,10 +455,11 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < XV; ++i) {
                 f32x4 v = xv[i];
-                if (a.mask_y) {
+                if (has_mask) {
                     const f32x4 my = mv[VEC ? i : 0];
+                    const float d = a.mask_drop ? mdv[i] : 1.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? mdv[i] : mdv[i] * a.mask_slope;
+                    for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? d : d * a.mask_slope;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = x_ok ? v[e] : 0.f;
@@ -436,7 +470,8 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 for (int i = 0; i < HV; ++i) {
                     const int row = h_row0 + i * HROWS;
                     float u = hv[i];
-                    if (a.mask_y) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
+                    const float d = a.mask_drop ? mdh[i] : 1.f;
+                    if (has_mask) u *= mhv[i] > 0.f ? d : d * a.mask_slope;
                     if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = h_ok ? u : 0.f;
                 }
             }
@@ -458,7 +493,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const bool ok = (okbits >> (8 + i)) & 1u;
             f32x4 v = xv[i];
             if (VEC) {
-                if (a.mask_y) {
+                if (has_mask) {
                     const f32x4 my = mv[VEC ? i : 0];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? mdv[i] : mdv[i] * a.mask_slope;
@@ -474,7 +509,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 const int row = h_row0 + i * HROWS;
                 const bool ok = (okbits >> (16 + i)) & 1u;
                 float u = hv[i];
-                if (a.mask_y) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
+                if (has_mask) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
                 if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = ok ? u : 0.f;
             }
         }
@@ -489,25 +524,34 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     EEGGAN_STAMP(0, 6);
+    auto advance = [&]() {
+        if (++p_chunk == nchunks) {
+            p_chunk = 0;
+            p_tile += gridDim.x;
+            setup_tile(p_tile);
+        }
+    };
+    // DEEP prefetches unconditionally (past the last step from one fixed address, the values are never
+    // committed): a branch around the loads would make the wait before each commit cover both stages.
     setup_tile(p_tile);
-    prefetch();
-    commit(smem);
+    prefetch(sa);
+    if (DEEP) {
+        advance();
+        prefetch(sb);
+    }
+    commit(sa, smem);
     __syncthreads();
     EEGGAN_STAMP(0, 7);
 
     int c_tile = blockIdx.x, c_chunk = 0;  // step being computed
-    for (int step = 0; step < nsteps; ++step) {
+    auto body = [&](const int step, Stage& s_issue, const Stage& s_commit) {
         const bool more = step + 1 < nsteps;
         EEGGAN_STAMP(step, 0);
-        if (more) {
-            if (++p_chunk == nchunks) {
-                p_chunk = 0;
-                p_tile += gridDim.x;
-                setup_tile(p_tile);
-            }
-            prefetch();
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
+        if (DEEP || more) {
+            advance();
+            prefetch(s_issue);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads above the MFMA block
         EEGGAN_STAMP(step, 1);
         const float* buf = smem + (step & 1) * BUF;
         const float* Ap = buf + (wm * RM * 32 + l31) * WLD + h * KH;
@@ -516,36 +560,53 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             // k-step s = (tap j, channel half g): this lane's 8 channels are 16 g + 8 h + i, at time l31 + j - 1
             const char* Wb = reinterpret_cast<const char*>(buf) + (wm * RM * 32 + l31) * WROWB + h * 16;
             const float* Bq = buf + CT * WLD + h * 8 * XLD + wn * RN * SUB + (4 - PAD) + l31;
+            // all LDS reads of this wave's k-steps first (a wave has at most one partner on its SIMD to hide their
+            // latency behind), then the splitting and the MFMAs
+            // (the weight fragments too where the registers allow it: one 32-channel row tile per wave)
+            constexpr int NSTEP = 6 / KS;
+            constexpr bool HOISTW = RM == 1;
+            float xr[NSTEP][RN][8];
+            bf16x8s wf[HOISTW ? NSTEP : 1][RM][3];
+            auto read_w = [&](int u, int s) {
 #pragma unroll
-            for (int s = kid * (6 / KS); s < (kid + 1) * (6 / KS); ++s) {
-                const int j = s >> 1, g = s & 1;
-                bf16x8s w1[RM], w2[RM], w3[RM];
+                for (int i = 0; i < RM; ++i)
 #pragma unroll
-                for (int i = 0; i < RM; ++i) {
-                    const char* wp = Wb + i * 32 * WROWB + s * 32;
-                    w1[i] = *reinterpret_cast<const bf16x8s*>(wp);
-                    w2[i] = *reinterpret_cast<const bf16x8s*>(wp + CT * WROWB);
-                    w3[i] = *reinterpret_cast<const bf16x8s*>(wp + 2 * CT * WROWB);
-                }
+                    for (int k = 0; k < 3; ++k)
+                        wf[HOISTW ? u : 0][i][k] = *reinterpret_cast<const bf16x8s*>(Wb + i * 32 * WROWB + s * 32 + k * CT * WROWB);
+            };
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) {
+                const int s = kid * NSTEP + u, j = s >> 1, g = s & 1;
+#pragma unroll
+                for (int n = 0; n < RN; ++n)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xr[u][n][i] = Bq[(16 * g + i) * XLD + n * SUB + j];
+                if (HOISTW) read_w(u, s);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NSTEP; ++u) {
+                if (!HOISTW) read_w(u, kid * NSTEP + u);
+                const bf16x8s(&w1)[RM][3] = wf[HOISTW ? u : 0];
 #pragma unroll
                 for (int n = 0; n < RN; ++n) {
                     bf16x8s x1, x2, x3;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         __bf16 p1, p2, p3;
-                        split3s(Bq[(16 * g + i) * XLD + n * SUB + j], p1, p2, p3);
+                        split3s(xr[u][n][i], p1, p2, p3);
                         x1[i] = p1;
                         x2[i] = p2;
                         x3[i] = p3;
                     }
 #pragma unroll
                     for (int i = 0; i < RM; ++i) {
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1[i], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w3[i], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w2[i], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1[i], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w2[i], acc[i][n], 0, 0, 0);
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1[i][0], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][2], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1[i][1], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, w1[i][0], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][1], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][0], acc[i][n], 0, 0, 0);
                     }
                 }
             }
@@ -686,10 +747,19 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and their consumers below it
         EEGGAN_STAMP(step, 3);
-        if (more) commit(smem + ((step + 1) & 1) * BUF);
+        if (more) commit(s_commit, smem + ((step + 1) & 1) * BUF);
         EEGGAN_STAMP(step, 4);
         __syncthreads();
         EEGGAN_STAMP(step, 5);
+    };
+    if (DEEP) {
+        for (int step = 0; step < nsteps; step += 2) {
+            body(step, sa, sb);
+            if (step + 1 >= nsteps) break;
+            body(step + 1, sb, sa);
+        }
+    } else {
+        for (int step = 0; step < nsteps; ++step) body(step, sa, sa);
     }
 }
 
@@ -715,11 +785,11 @@ int num_cus() {
 
 namespace {
 
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, bool SPLIT = false>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, bool SPLIT = false, int MASK = -1>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
     constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
-    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT>;
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK>;
     static int per_cu = 0;  // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once)
     if (per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -766,9 +836,13 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     if constexpr (K == 3) {
         // predicate-free layers: products from bf16 pieces.  The narrow tile is 32 channels x 2 subtiles there (as many
         // tiles as 64 x 1): with the weight chunk as three piece planes that is what still fits twice on a CU.
-        if (full && split_products())
-            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true>(a, st)
-                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true>(a, st);
+        if (full && split_products()) {
+            if (a.mask_y)
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true, 1>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true, 1>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true, 0>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true, 0>(a, st);
+        }
     }
     if (big)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
         return full ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2>(a, st) : launch_fwd<K, 64, 4, 32, 1, 4, true>(a, st);
