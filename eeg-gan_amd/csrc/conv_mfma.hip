@@ -907,7 +907,13 @@ struct WgradArgs {
     int nsplit;
     int iters;    // subtile pairs per split
     int vec;
+#ifdef EEGGAN_TRACE
+    unsigned long long* trace;  // as ConvArgs::trace
+#endif
 };
+#ifdef EEGGAN_TRACE
+unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next weight-gradient launch writes its stamps)
+#endif
 
 // FULL: Cin % 64 == 0, Cout % 64 == 0, T % 32 == 0 and T % 4 == 0: staging without predicates on
 // channels or time, with one wave-uniform (sample, time) decode per iteration, two LDS buffers and a
@@ -928,8 +934,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     const int lane = tid & 63;
     const int l31 = lane & 31;
     const int h = lane >> 5;
+    // SPLIT runs eight waves, two per SIMD: wave w and wave w + 4 share an output tile and take one subtile of every
+    // pair each (their sums meet through LDS at the end).  On the bf16 pipe the matrix work of an iteration is
+    // shorter than the splitting that feeds it, and a wave alone on its SIMD runs the two one after the other.
+    constexpr int NTHR = SPLIT ? 512 : 256;
     const int wave = tid >> 6;
-    const int cot = wave >> 1, cit = wave & 1;
+    const int part = SPLIT ? wave >> 2 : 0;
+    const int cot = (wave >> 1) & 1, cit = wave & 1;
     const int co0 = (region / a.nci) * 64;
     const int ci0 = (region % a.nci) * 64;
     const bool do_bias = a.ws_b != nullptr && ci0 == 0 && cit == 0;
@@ -950,8 +961,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         if constexpr (SPLIT) {
             const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h;
             const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h;
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) {
+            {
+                const int n = part;  // this wave's subtile of the pair
 #pragma unroll
                 for (int tb = 0; tb < 32; tb += 16) {
                     // this lane's 8 time steps tb + 8h .. +7 of the gradient row, and the 10 input samples around them
@@ -1024,10 +1035,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     if (FULL) {
         // this thread's items: 16-byte item (row = r0 + 16 i, subtile n, floats 4q..4q+3) of both tiles,
         // and one halo sample (row hr, subtile hn, left/right) of the x tile
+        constexpr int RSTEP = NTHR / 16;   // rows covered by one pass of the workgroup's threads
+        constexpr int NI = 64 / RSTEP;     // 16-byte items per thread and tile
         const int q = tid & 7, n = (tid >> 3) & 1, r0 = tid >> 4;
-        const int hs = tid & 1, hn = (tid >> 1) & 1, hr = tid >> 2;
-        f32x4 gv[4], xv[4], mv[4];
-        float md[4], hv = 0.f;
+        const int hs = tid & 1, hn = (tid >> 1) & 1, hr = tid >> 2;  // (halo items: the first 256 threads)
+        f32x4 gv[NI], xv[NI], mv[NI];
+        float md[NI], hv = 0.f;
         bool ok = false, hok = false;
 
         auto issue = [&](int it) {  // loads only; consumers live in commit()
@@ -1048,25 +1061,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             const float* mp = a.mask_y ? a.mask_y + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q : a.gy;
             const float* dp = a.mask_drop ? a.mask_drop + b * a.Cout + co0 + r0 : a.gy;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long long o = (long long)(16 * i) * a.T;
+            for (int i = 0; i < NI; ++i) {
+                const long long o = (long long)(RSTEP * i) * a.T;
                 gv[i] = *reinterpret_cast<const f32x4*>(gp + o);
                 xv[i] = *reinterpret_cast<const f32x4*>(xp + o);
                 if (a.mask_y) {  // wave-uniform
                     mv[i] = *reinterpret_cast<const f32x4*>(mp + o);
-                    md[i] = dp[a.mask_drop ? 16 * i : 0];
+                    md[i] = dp[a.mask_drop ? RSTEP * i : 0];
                 }
             }
             if (K > 1) {
                 const int hb = hn ? bb[1] : bb[0], ht0 = hn ? tt[1] : tt[0];
                 const int t = ht0 + (hs ? 32 : -1);
-                hok = (hn ? vv[1] : vv[0]) && t >= 0 && t < a.T;
+                hok = (hn ? vv[1] : vv[0]) && t >= 0 && t < a.T && hr < 64;
                 hv = a.x[hok ? ((long long)hb * a.Cin + ci0 + hr) * a.T + t : 0];
             }
         };
         auto commit = [&](float* Gs, float* Xs) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 f32x4 g = gv[i], x = xv[i];
                 if (a.mask_y) {
                     const float d = a.mask_drop ? md[i] : 1.f;
@@ -1078,27 +1091,34 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                     g[e] = ok ? g[e] : 0.f;
                     x[e] = ok ? x[e] : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(Gs + (r0 + 16 * i) * LD + n * SUB + 4 + 4 * q) = g;
-                *reinterpret_cast<f32x4*>(Xs + (r0 + 16 * i) * LD + n * SUB + 4 + 4 * q) = x;
+                *reinterpret_cast<f32x4*>(Gs + (r0 + RSTEP * i) * LD + n * SUB + 4 + 4 * q) = g;
+                *reinterpret_cast<f32x4*>(Xs + (r0 + RSTEP * i) * LD + n * SUB + 4 + 4 * q) = x;
             }
-            if (K > 1) Xs[hr * LD + hn * SUB + (hs ? 36 : 3)] = hok ? hv : 0.f;
+            if (K > 1 && hr < 64) Xs[hr * LD + hn * SUB + (hs ? 36 : 3)] = hok ? hv : 0.f;
         };
 
+        EEGGAN_STAMP(0, 6);
         if (it0 < it1) {
             issue(it0);
             commit(smem, smem + 64 * LD);
         }
         __syncthreads();
+        EEGGAN_STAMP(0, 7);
         for (int it = it0; it < it1; ++it) {
             const bool more = it + 1 < it1;
             float* cur = smem + ((it - it0) & 1) * BUF;
             float* nxt = smem + ((it - it0 + 1) & 1) * BUF;
+            EEGGAN_STAMP(it - it0, 0);
             if (more) issue(it + 1);
             __builtin_amdgcn_sched_barrier(0);
+            EEGGAN_STAMP(it - it0, 1);
             mfma_block(cur, cur + 64 * LD);
+            EEGGAN_STAMP(it - it0, 2);
             __builtin_amdgcn_sched_barrier(0);
             if (more) commit(nxt, nxt + 64 * LD);
+            EEGGAN_STAMP(it - it0, 3);
             __syncthreads();
+            EEGGAN_STAMP(it - it0, 4);
         }
     } else {
         float* Gs = smem;            // [64][LD]
@@ -1123,6 +1143,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         }
     }
 
+    if (SPLIT) {
+        // waves 4..7 hand their sums to waves 0..3 (the staging buffers are free: every path above ends in a barrier
+        // or never used them)
+        float* red = smem + ((wave & 3) * (K * 16 + 1)) * 64 + lane;
+        if (part == 1) {
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64] = acc[j][r];
+            red[K * 16 * 64] = bsum;
+        }
+        __syncthreads();
+        if (part == 1) return;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64];
+        bsum += red[K * 16 * 64];
+    }
     const long long E = (long long)a.Cout * a.Cin * K;
     float* slab = a.ws + (long long)split * E;
     const int ci = ci0 + cit * 32 + l31;
@@ -1142,7 +1181,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
 }
 
 template <int K, bool FULL, bool SPLIT = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_kernel(WgradArgs a) {
     wgrad_body<K, FULL, SPLIT>(a, blockIdx.x, blockIdx.y);
 }
 
@@ -1158,7 +1197,7 @@ struct WgradPack {
 };
 
 template <int K, bool FULL, bool SPLIT = false>
-__global__ __launch_bounds__(256) void conv_wgrad_multi_kernel(WgradPack pk) {
+__global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
     while (k + 1 < pk.n && blk >= pk.first[k + 1]) ++k;
@@ -1353,6 +1392,9 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
     a.NS = B * a.ST;
     a.nci = p.nci; a.nsplit = p.nsplit; a.iters = p.iters;
     a.vec = (T % 4 == 0) ? 1 : 0;
+#ifdef EEGGAN_TRACE
+    a.trace = g_wgrad_trace;
+#endif
     constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);  // one buffer: gy tile + x tile
     const bool full = Cin % 64 == 0 && Cout % 64 == 0 && T % 32 == 0;
     dim3 grid(p.nsplit, p.regions);
@@ -1368,7 +1410,7 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
             ready = true;
         }
         if (split_products())
-            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, true>), grid, dim3(256), 2 * lds1, st, a);
+            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, true>), grid, dim3(512), 2 * lds1, st, a);
         else
             hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
     } else if (K == 3) {
@@ -1529,6 +1571,9 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 const long long it = iters > plan[k].iters ? iters : plan[k].iters;
                 const int nsplit = (int)((pairs[k] + it - 1) / it);
                 WgradArgs& a = pk.j[k];
+#ifdef EEGGAN_TRACE
+                a.trace = nullptr;
+#endif
                 a.x = j.x; a.gy = j.gy; a.mask_y = j.mask_y; a.mask_drop = j.mask_y ? j.mask_drop : nullptr;
                 a.mask_slope = j.mask_slope;
                 a.ws = static_cast<float*>(j.workspace);
@@ -1561,7 +1606,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                     ready = true;
                 }
                 if (split_products())
-                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, true>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
             } else if (v == 1) {
