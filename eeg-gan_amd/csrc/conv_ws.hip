@@ -489,7 +489,13 @@ int launch_rm(const ConvArgs& a, hipStream_t st) {
     const bool halves = a.act != ACT_LRELU_PN && (a.NS < waves || half < whole);  // (the norm needs all channels in one unit)
     if constexpr (FULL && K == 3) {
         // (EEGGAN_FP32_MFMA=1 in the environment keeps the fp32 matrix instructions: comparison runs)
-        if (split_products()) return halves ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
+        if (split_products()) {
+            // With the split products a unit's cost is mostly the splitting of its input, which a whole unit does
+            // once for both halves of the output channels: a whole unit counts 1.3 half units, not 2 (i.e. half
+            // units only while they fit one round of the chip's waves; measured +1.2 % steps/s, 1.6 the same).
+            const bool halves_s = a.act != ACT_LRELU_PN && half * 10 < (whole / 2) * 13;
+            return halves_s ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
+        }
     }
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);
 }
