@@ -122,7 +122,7 @@ def conv_roofline(dev, batch, T):
     # HBM bytes per launch from the PMC passes kept in profiles/*pmc_conv_ws_64x64_T1920_B32.csv
     # (2 x FETCH_SIZE + WRITE_SIZE = 2 x 11588.4 KiB + 15360 KiB; the algorithmic figure is 31.5 MB:
     # input + output once, weights, multipliers).  Only valid for the profiled shape.
-    traffic = (2 * 11647.9375 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
+    traffic = (2 * 9822.5625 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
     # The kernel forms every fp32 product from three bf16 pieces per operand (six bf16 MFMAs per 16
     # reduction indices, fp32-exact to 2^-24): `achieved`/`frac` price the ALGORITHMIC fp32 flops against
     # the fp32 matrix peak (the arithmetic type of the path); `pipe_frac` prices the six-fold executed
