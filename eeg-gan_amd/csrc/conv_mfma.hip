@@ -544,9 +544,29 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     EEGGAN_STAMP(0, 7);
 
     int c_tile = blockIdx.x, c_chunk = 0;  // step being computed
+    // bias and multiplier of this lane's output rows, loaded at the start of a tile's LAST step: in the epilogue
+    // their latency would be exposed (through an always-valid pointer, neutralised by a select at their use)
+    float pre_b[RM], pre_d[RM][RN];
     auto body = [&](const int step, Stage& s_issue, const Stage& s_commit) {
         const bool more = step + 1 < nsteps;
         EEGGAN_STAMP(step, 0);
+        if (c_chunk + 1 == nchunks) {
+            const int ty = c_tile / tiles_x, tx = c_tile - ty * tiles_x;
+            const float* bp = a.bias ? a.bias : a.w;
+            const float* dp = a.drop ? a.drop : a.w;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int co = ty * CT + (wm * RM + i) * 32 + l31;
+                const int cc = co < a.Cout ? co : 0;
+                pre_b[i] = bp[a.bias ? cc : 0];
+#pragma unroll
+                for (int n = 0; n < RN; ++n) {
+                    const int sub = tx * NT + wn * RN + n;
+                    const int b = sub < a.NS ? sub / a.ST : 0;
+                    pre_d[i][n] = dp[a.drop ? b * a.Cout + cc : 0];
+                }
+            }
+        }
         if (DEEP || more) {
             advance();
             prefetch(s_issue);
@@ -641,8 +661,6 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const int co0 = ty * CT;
             const bool full = co0 + CT <= a.Cout;
             const bool has_bias = a.bias != nullptr, has_drop = a.drop != nullptr;
-            const float* bp = has_bias ? a.bias : a.w;
-            const float* dp = has_drop ? a.drop : a.w;
             if (KS > 1) {
                 // waves kid > 0 hand their partial sums to the kid = 0 wave of the same (wm, wn)
                 float* red = smem + 2 * BUF + ((wave % (WM * WN)) * RM * RN) * 16 * 64 + lane;
@@ -683,8 +701,8 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                         const bool cok = sok && (full || co < a.Cout);
                         const int cc = cok ? co : 0;
                         const int bc = cok ? b : 0;
-                        const float bb = has_bias ? bp[cc] : 0.f;
-                        const float dd = has_drop ? dp[bc * a.Cout + cc] : 1.f;
+                        const float bb = has_bias ? pre_b[i] : 0.f;
+                        const float dd = has_drop ? pre_d[i][n] : 1.f;
                         const long long row = ((long long)bc * a.Cout + cc) * a.T;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
