@@ -1450,21 +1450,70 @@ struct ReducePack {
     int n;
 };
 
+// A job whose slabs are whole 16-byte items takes 256 elements per workgroup, four per thread: a wave's load is then
+// 1 KB of one slab instead of 256 bytes (the slabs of a job lie E floats apart, so short pieces are scattered
+// reads).  Same summation order per element either way.
+__host__ __device__ inline bool reduce_vec(const eeggan_reduce_job& j) {
+    return j.elems % 4 == 0 && ((uintptr_t)j.slabs & 15) == 0 && ((uintptr_t)j.out & 15) == 0;
+}
+__host__ __device__ inline long long reduce_blocks(const eeggan_reduce_job& j) {
+    return reduce_vec(j) ? (j.elems + 255) / 256 : (j.elems + 63) / 64;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReducePack pk) {
-    __shared__ double part[4][64];
+    __shared__ double part[4][256];
     long long blk = blockIdx.x;
     int k = 0;
     for (; k < pk.n; ++k) {
-        const long long nb = (pk.j[k].elems + 63) / 64;
+        const long long nb = reduce_blocks(pk.j[k]);
         if (blk < nb) break;
         blk -= nb;
     }
     if (k == pk.n) return;
     const eeggan_reduce_job job = pk.j[k];
     const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const long long i = blk * 64 + el, E = job.elems;
     const int nsplit = job.nsplit;
     const float* ws = job.slabs;
+    if (reduce_vec(job)) {  // workgroup-uniform
+        const long long i = blk * 256 + 4 * el, E = job.elems;
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (i < E) {
+            int s = sg;
+            for (; s + 28 < nsplit; s += 32) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(ws + (long long)(s + 4 * u) * E + i);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a4[e] += (double)v[u][e];
+            }
+            for (; s < nsplit; s += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * E + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[e] += (double)v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[sg][4 * el + e] = a4[e];
+        __syncthreads();
+        if (sg == 0 && i < E) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * el + e;
+                o[e] = (float)(((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * (double)job.scale);
+            }
+            if (job.beta != 0.f) {
+                const f32x4 old = *reinterpret_cast<const f32x4*>(job.out + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = job.beta * old[e] + o[e];
+            }
+            *reinterpret_cast<f32x4*>(job.out + i) = o;
+        }
+        return;
+    }
+    const long long i = blk * 64 + el, E = job.elems;
     double acc = 0.0;
     if (i < E) {
         int s = sg;
@@ -1658,7 +1707,7 @@ extern "C" int eeggan_wgrad_reduce_multi(const eeggan_reduce_job* jobs, int njob
             for (int k = 0; k < i; ++k)
                 EEGGAN_REQUIRE(pk.j[k].out != pk.j[i].out, "wgrad_reduce_multi: jobs %d and %d write the same output",
                                first + k, first + i);
-            blocks += (pk.j[i].elems + 63) / 64;
+            blocks += reduce_blocks(pk.j[i]);
         }
         EEGGAN_REQUIRE(blocks < (1ll << 31), "wgrad_reduce_multi: too many elements");
         hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pk);
