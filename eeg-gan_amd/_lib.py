@@ -57,6 +57,7 @@ SIGNATURES = {
     "eeggan_resample_quads": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "eeggan_mbstd_workspace": (_sz, [_i, _i, _i, _i]),
     "eeggan_mbstd_fwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_fwd_static": (_i, [_f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_wgan_gp_loss_fwd": (_i, [_f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),

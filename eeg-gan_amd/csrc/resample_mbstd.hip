@@ -2,6 +2,8 @@
 // MinibatchStddev layer with its first- and second-order backward.
 #include "common.h"
 
+#include <mutex>
+
 namespace eeggan {
 namespace {
 
@@ -249,6 +251,36 @@ int mb_check(const char* what, int B, int C, int T, int group, int* G, int* M) {
     return 0;
 }
 
+// ---- built-in scratch for the entry point that allocates nothing ------------------------------------
+// Partial sums of eeggan_mbstd_fwd_static: one float per (group member, element chunk).  The array lives
+// in the code object, so every GPU the library runs on holds its own copy at its own address until the
+// process ends.  Host code never uses the array's name as an address: the name is a host-side stand-in,
+// and the per-device address comes from hipGetSymbolAddress, once per device.
+constexpr size_t MB_STATIC_FLOATS = 65536;  // 256 KiB per GPU
+static __device__ __align__(256) float scratch[MB_STATIC_FLOATS];
+
+constexpr int MB_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[MB_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (resolved at the first call on that device).
+int scratch_for_current_device(const char* what, float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    EEGGAN_REQUIRE(e == hipSuccess, "%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
+    EEGGAN_REQUIRE(dev >= 0 && dev < MB_MAX_DEVICES, "%s: device index %d outside [0, %d)", what, dev, MB_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        EEGGAN_REQUIRE(e == hipSuccess && ptr != nullptr, "%s: cannot resolve the built-in scratch buffer on device %d: %s",
+                       what, dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
 }  // namespace
 }  // namespace eeggan
 
@@ -321,6 +353,26 @@ extern "C" int eeggan_mbstd_fwd(const float* x, float* out, void* workspace, int
     hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, n, T, nch,
                        1.f / (float)n);
     return check_launch("mbstd_fwd finalize");
+}
+
+extern "C" int eeggan_mbstd_fwd_static(const float* x, float* out, int B, int C, int T, int group, void* stream) {
+    int G, M;
+    if (mb_check("mbstd_fwd_static", B, C, T, group, &G, &M)) return 1;
+    EEGGAN_REQUIRE(x && out, "mbstd_fwd_static: null pointer");
+    const int n = C * T, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
+    const size_t need = (size_t)M * (size_t)nch;
+    EEGGAN_REQUIRE(need <= MB_STATIC_FLOATS,
+                   "mbstd_fwd_static: B=%d, C=%d, T=%d needs %zu floats of scratch, the built-in buffer holds %zu "
+                   "(use eeggan_mbstd_fwd with a workspace)", B, C, T, need, MB_STATIC_FLOATS);
+    float* ws = nullptr;
+    if (scratch_for_current_device("mbstd_fwd_static", &ws)) return 1;
+    // every partial sum the finalize kernel reads is written by the first kernel of this call: nothing of
+    // an earlier call's contents is read, so nothing needs clearing
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, C, T);
+    if (check_launch("mbstd_fwd_static")) return 1;
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, n, T, nch,
+                       1.f / (float)n);
+    return check_launch("mbstd_fwd_static finalize");
 }
 
 extern "C" int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,

@@ -200,6 +200,14 @@ int eeggan_resample_quads(const float* x, const int32_t* base, const float* coef
 size_t eeggan_mbstd_workspace(int B, int C, int T, int group);
 int eeggan_mbstd_fwd(const float* x, float* out, void* workspace, int B, int C, int T, int group,
                      void* stream);
+/* eeggan_mbstd_fwd for callers that cannot allocate device memory (code under hipGraph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The partial
+ * sums live in a 256 KiB buffer built into the library (one copy per GPU, held until the process ends), so
+ * there is no workspace argument and the call makes no allocation of any kind; B/min(B,group) *
+ * ceil(C*T/256) must not exceed 65536 floats, otherwise the call fails with a message and launches nothing.
+ * All calls on one GPU share that buffer: calls that overlap on one GPU (two streams) race.  The first call
+ * on a device resolves the buffer's address and must not be made while a stream is capturing. */
+int eeggan_mbstd_fwd_static(const float* x, float* out, int B, int C, int T, int group, void* stream);
 int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
                      void* stream);
 int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
