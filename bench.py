@@ -44,9 +44,6 @@ def parse():
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--alpha", type=float, default=ALPHA, help="fade-in factor (< 1: mid-transition step)")
-    ap.add_argument("--lockstep-penalty", action="store_true",
-                    help="run the critic pass over the penalty's interpolates in lockstep with the stacked "
-                         "reals+fakes pass instead of on its own (comparison; slower, see losses.discriminator_loss)")
     ap.add_argument("--per-iteration-fakes", action="store_true",
                     help="one generator pass per critic iteration instead of one per step (comparison runs)")
     ap.add_argument("--host-inputs", action="store_true",
@@ -61,7 +58,7 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_
     from eeggan_amd.parallel import DataParallelStep
     from eeggan_amd.graphs import GraphedTrainer
     from eeggan_amd.trainer import Trainer
-    from oracle.ref_cpu import synthetic_eeg  # input synthesis only (same generator as the CPU leg)
+    from eeggan_amd.dataset import synthetic_eeg
 
     g, d = config.build_models(config.RANDOM_SEED)
     g, d = g.to(dev), d.to(dev)
@@ -197,8 +194,6 @@ def main():
     tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs)
     if args.per_iteration_fakes:
         tr.batch_fakes = False
-    if args.lockstep_penalty:
-        tr.d_loss = functools.partial(tr.d_loss, lockstep_penalty=True)
 
     def barrier():
         if dist is not None:

@@ -48,6 +48,7 @@ SIGNATURES = {
     "eeggan_lrelu_drop_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _st]),
     "eeggan_pixelnorm_drop_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _st]),
     "eeggan_pixelnorm_drop_bwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_scaled_tanh": (_i, [_f, _f, _sz, _fl, _st]),
     "eeggan_tanh_bwd": (_i, [_f, _f, _f, _sz, _fl, _st]),
     "eeggan_axpby": (_i, [_f, _fl, _f, _fl, _f, _sz, _st]),
     "eeggan_blend": (_i, [_f, _f, _f, _i, _f, _sz, _st]),

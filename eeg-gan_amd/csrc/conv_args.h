@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
+
 namespace eeggan {
 
 struct ConvArgs {
@@ -52,8 +54,13 @@ constexpr int ACT_LRELU_PN = 4;
 // Returns -1 when the shape is not covered, otherwise the launch status.
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st);
 bool conv_ws_covers(const ConvArgs& a, int K);
-int num_cus();
+int num_cus();  // compute units of the CURRENT device
 bool split_products();
+// One-time launch set-up (LDS opt-in, occupancy) is kept per device in arrays of this many atomics: the
+// entry points are called from autograd's backward thread as well, and a process may drive several GPUs.
+// The set-up calls are idempotent, so two threads racing through one only repeat it.
+constexpr int MAX_DEVICES = 64;
+int current_device();  // hipGetDevice, clamped to [0, MAX_DEVICES)
 // Bandwidth-bound form for 1x1 convs with at most 8 input or output channels (conv_thin.hip); -1 when
 // the shape is not covered.
 int launch_conv_thin(const ConvArgs& a, int K, hipStream_t st);

@@ -790,15 +790,21 @@ bool split_products() {
     return on;
 }
 
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
+
 int num_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
+    static std::atomic<int> cus[MAX_DEVICES];
+    const int dev = current_device();
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
-    return cus;
+    return n;
 }
 
 namespace {
@@ -808,7 +814,10 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
     constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
     auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK>;
-    static int per_cu = 0;  // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once)
+    // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once per device)
+    static std::atomic<int> per_cu_dev[MAX_DEVICES];
+    std::atomic<int>& slot = per_cu_dev[current_device()];
+    int per_cu = slot.load(std::memory_order_acquire);
     if (per_cu == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -820,6 +829,7 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), 64 * WM * WN * KS, lds) != hipSuccess || n < 1)
             n = 1;
         per_cu = n > 4 ? 4 : n;
+        slot.store(per_cu, std::memory_order_release);
     }
     const long long ntiles = (long long)((a.NS + NT - 1) / NT) * ((a.Cout + CT - 1) / CT);
     long long grid = (long long)num_cus() * per_cu;
@@ -1312,6 +1322,10 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     EEGGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
                        (!mask_y || (reinterpret_cast<uintptr_t>(mask_y) & 15) == 0),
                    "conv1d: x, w and mask_y must be 16-byte aligned");
+    // with T % 4 == 0 the output and the mask of the output are moved in 16-byte pieces as well
+    EEGGAN_REQUIRE(T % 4 != 0 || ((reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                                  (!act_aux || (reinterpret_cast<uintptr_t>(act_aux) & 15) == 0)),
+                   "conv1d: y and act_aux must be 16-byte aligned when T is a multiple of 4");
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.drop = drop; a.y = y;
     a.mask_y = mask_y; a.mask_drop = mask_y ? mask_drop : nullptr; a.mask_slope = mask_slope;
@@ -1417,15 +1431,17 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
     const bool full = Cin % 64 == 0 && Cout % 64 == 0 && T % 32 == 0;
     dim3 grid(p.nsplit, p.regions);
     if (K == 3 && full) {
-        static bool ready = false;  // two buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once)
-        if (!ready) {
+        // two buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once per device)
+        static std::atomic<bool> ready_dev[MAX_DEVICES];
+        std::atomic<bool>& ready = ready_dev[current_device()];
+        if (!ready.load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
             EEGGAN_REQUIRE(e == hipSuccess, "%s: cannot reserve LDS: %s", what, hipGetErrorString(e));
-            ready = true;
+            ready.store(true, std::memory_order_release);
         }
         if (split_products())
             hipLaunchKernelGGL((conv_wgrad_kernel<3, true, true>), grid, dim3(512), 2 * lds1, st, a);
@@ -1661,8 +1677,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
             }
             for (int k = n; k <= WG_MAXJ; ++k) pk.first[k] = first;
             if (v == 0) {
-                static bool ready = false;  // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once)
-                if (!ready) {
+                // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once per device)
+                static std::atomic<bool> ready_dev[MAX_DEVICES];
+                std::atomic<bool>& ready = ready_dev[current_device()];
+                if (!ready.load(std::memory_order_acquire)) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     if (e == hipSuccess)
@@ -1670,7 +1688,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad_partial_multi: cannot reserve LDS: %s",
                                    hipGetErrorString(e));
-                    ready = true;
+                    ready.store(true, std::memory_order_release);
                 }
                 if (split_products())
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, true>), dim3(first), dim3(512), 2 * lds1, st, pk);

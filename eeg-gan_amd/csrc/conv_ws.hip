@@ -458,15 +458,17 @@ template <int K, bool MASKED, bool FULL, int RM, bool SPLIT = false>
 int launch(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)((SPLIT ? 3 * WPLANE / 4 : 64 * (64 * K + 4)) + WS_WAVES * XREG) * sizeof(float);
     auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM, SPLIT>;
-    static bool ready = false;  // opt in to > 64 KiB of dynamic LDS (once)
-    if (!ready) {
+    // opt in to > 64 KiB of dynamic LDS (once per device)
+    static std::atomic<bool> ready_dev[MAX_DEVICES];
+    std::atomic<bool>& ready = ready_dev[current_device()];
+    if (!ready.load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("conv1d: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
             return 1;
         }
-        ready = true;
+        ready.store(true, std::memory_order_release);
     }
     ConvArgs b = a;
     const long long units = (long long)a.NS * (3 - RM);

@@ -258,6 +258,24 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256) void scaled_tanh_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n,
+                                                          float scale) {
+    constexpr int W = VEC ? 4 : 1;
+    const size_t items = n / W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        if (VEC) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = tanhf(v[k] * scale);
+            reinterpret_cast<f32x4*>(y)[i] = o;
+        } else {
+            y[i] = tanhf(x[i] * scale);
+        }
+    }
+}
+
 // out = ca*a + cb*b.  `alpha` != nullptr: the coefficients come from the fade-in factor in device
 // memory (mode 0: ca = alpha, cb = 1 - alpha; 1: ca = alpha; 2: ca = 1 - alpha) -- the same loop body as
 // the by-value form, so both give bit-identical results for equal coefficients.
@@ -390,6 +408,18 @@ extern "C" int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_
         hipLaunchKernelGGL(tanh_bwd_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), gy, y, gc, n,
                            scale);
     return check_launch("tanh_bwd");
+}
+
+extern "C" int eeggan_scaled_tanh(const float* x, float* y, size_t n, float scale, void* stream) {
+    EEGGAN_REQUIRE(x && y && n > 0, "scaled_tanh: null pointer or empty");
+    const bool vec = (n % 4 == 0) && aligned16(x) && aligned16(y);
+    if (vec)
+        hipLaunchKernelGGL(scaled_tanh_kernel<true>, dim3(blocks_stream(n / 4)), dim3(256), 0, as_stream(stream), x, y, n,
+                           scale);
+    else
+        hipLaunchKernelGGL(scaled_tanh_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), x, y, n,
+                           scale);
+    return check_launch("scaled_tanh");
 }
 
 extern "C" int eeggan_axpby(const float* a, float ca, const float* b, float cb, float* out, size_t n, void* stream) {

@@ -8,6 +8,7 @@ Reading, channel picking and normalising the recordings (dataset.py:53-118) stay
 happens once, before training."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops
@@ -63,3 +64,20 @@ class DepthResampler:
         if self.model_depth != self.max_dataset_depth:
             x = self.create_datapoint_from_depth(x, self.model_depth)
         return {"x": self.alpha_fade(x)}
+
+
+def synthetic_eeg(batch: int, channels: int, length: int, rng: np.random.Generator, full_rate_hz: float = 60.0,
+                  full_length: int = 1920) -> np.ndarray:
+    """Stand-in recordings for benchmarks and smoke runs when no dataset is at hand: [batch, channels, length]
+    float32 windows, each channel six sinusoids of 1-30 Hz with 1/f amplitudes and random phases plus white
+    noise (sigma 0.1), sampled at the rate of the stage whose window is ``length`` long
+    (``full_rate_hz * length / full_length``), then min-max scaled to [-1, 1] per window like the
+    reference's recordings (dataset.py:139-144)."""
+    rate = full_rate_hz * length / full_length
+    time = np.arange(length)[None, None, None, :] / rate
+    freq = rng.uniform(1.0, 30.0, size=(batch, channels, 6, 1))
+    phase = rng.uniform(0, 2 * np.pi, size=(batch, channels, 6, 1))
+    x = (np.sin(2 * np.pi * freq * time + phase) / freq).sum(axis=2)
+    x = x + rng.normal(0, 0.1, size=(batch, channels, length))
+    lo, hi = x.min(axis=(1, 2), keepdims=True), x.max(axis=(1, 2), keepdims=True)
+    return ((x - lo) / (hi - lo) * 2.0 - 1.0).astype(np.float32)

@@ -40,6 +40,9 @@ class GraphedCall:
 
     def __call__(self):
         self.graph.replay()
+        # a replay may step an optimizer (weights change with no Python in between) and rewrites the shared
+        # flipped-weight views with the weights it started from: eager code that runs next must rebuild them
+        ops.bump_weights_epoch()
         return self.out
 
 

@@ -103,7 +103,7 @@ class ScaledTanh(nn.Tanh):
         self.scale = scale
 
     def forward(self, x):
-        raise NotImplementedError("ScaledTanh runs fused into the preceding GeneralConv (see network.ToRgb)")
+        return ops.scaled_tanh(x, self.scale)
 
 
 class GDropLayer(nn.Module):
@@ -144,9 +144,6 @@ class MinibatchStddev(nn.Module):
             return x
         if x.shape[2] > self.stride_size:
             raise NotImplementedError("MinibatchStddev: more than one temporal window is not supported")
-        if isinstance(x, ops.Parts):  # lockstep passes: statistics per part (and per minibatch inside a part)
-            return x.like([ops.minibatch_stddev(t, int(min(t.shape[0] // seg, self.group_size)), seg)
-                           for t, seg in zip(x.t, x.segments)])
         per_segment = x.shape[0] // _segments
         return ops.minibatch_stddev(x, int(min(per_segment, self.group_size)), _segments)
 
@@ -248,35 +245,9 @@ class GeneralConv(nn.Module):
             return None
         return self.drop.sample(x.shape[0], self.conv.conv.out_channels, x.device)
 
-    def _forward_parts(self, x):
-        """Critic-style layer (no norm) on lockstep parts: one draw of multipliers for all parts, so that
-        they lie back to back like the activations."""
-        c = self.conv
-        w, b, s = c.conv.weight, c.conv.bias, c.scale
-        if self.act_norm is not None:
-            raise NotImplementedError("lockstep parts are a critic-path feature (no activation norm)")
-        kind = c.kind(x.t[0])
-        slope = float(max(self.act_alpha, 0.0))
-        sizes = [t.shape[0] for t in x.t]
-        if self.drop is not None and self.act_alpha >= 0:
-            r = self.drop.sample(sum(sizes), c.conv.out_channels, x.device)
-            drops = [None] * len(sizes) if r is None else list(torch.split(r, sizes))
-        else:
-            drops = [None] * len(sizes)
-        if kind == "same":
-            act = ACT_LRELU if self.act_alpha >= 0 else ACT_NONE
-            if act == ACT_NONE and self.drop is not None:
-                raise NotImplementedError("linear conv with drop is not supported")
-            return x.like(ops.conv1d_parts(x.t, w, b, drops, s, act, slope, flip=c._flip))
-        if kind == "tail" and self.act_alpha >= 0:
-            return x.like([ops.tail_conv(t, w, b, d, s, slope) for t, d in zip(x.t, drops)])
-        raise NotImplementedError("this layer form is not available for lockstep parts")
-
     def forward(self, x, y=None, z=None, conv_noise=None, _tanh_scale=None):
         if conv_noise is not None:
             raise NotImplementedError("per-channel conv noise is not supported")
-        if isinstance(x, ops.Parts):
-            return self._forward_parts(x)
         c = self.conv
         w, b, s = c.conv.weight, c.conv.bias, c.scale
         kind = c.kind(x)

@@ -77,18 +77,13 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
                        iwass_drift_epsilon: float, grad_lambda: float, iwass_target: float,
                        mixing: Optional[torch.Tensor] = None, stack_real_fake: Optional[bool] = None,
-                       fake: Optional[torch.Tensor] = None, lockstep_penalty: bool = False):
+                       fake: Optional[torch.Tensor] = None):
     """WGAN-GP critic loss.  ``mixing`` optionally supplies the per-sample interpolation factors
     [B, 1, 1] (otherwise drawn like the reference does); used by parity tests.  ``stack_real_fake``:
     evaluate reals and fakes in one stacked critic pass (default: when GDrop noise is drawn on the device).
     ``fake``: fakes generated beforehand from ``z`` with the current generator (a trainer may generate
     the fakes of all critic iterations of a step in one pass: the generator does not change between
-    them, reference trainer.py:83-91); ``gen`` is then not called.  ``lockstep_penalty`` (off by default):
-    the critic pass over the penalty's interpolates runs in lockstep with the stacked pass, one launch
-    per layer for both (the reference runs it third, losses.py:113).  It removes ~15 % of the launches
-    of an iteration, but a batch of 3 B samples divides unevenly over the chip where 2 B and B divide
-    evenly (e.g. 1.5 rounds of tiles per layer instead of 1 and 0.5), which costs more than the launches
-    save: measured 11 % slower at every stage, so the trainers leave it off."""
+    them, reference trainer.py:83-91); ``gen`` is then not called."""
     if loss_type != "wgan_gp":
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
@@ -98,26 +93,6 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
     real_x = real["x"] if isinstance(real, dict) else real
     if stack_real_fake is None:
         stack_real_fake = layers.get_drop_mode() == "device"
-    if lockstep_penalty and not stack_real_fake:
-        raise ValueError("lockstep_penalty needs stack_real_fake")
-    if lockstep_penalty:
-        if fake is None:
-            with torch.no_grad():
-                g_, _ = gen(z)
-            fake_x = g_["x"]
-        else:
-            fake_x = fake
-        n = real_x.size(0)
-        # [reals; fakes; interpolates] in one buffer: the interpolates are a leaf of their own (their
-        # pass is differentiated twice), the layers see adjacent parts and run one launch for both
-        xin = torch.empty((3 * n,) + tuple(real_x.shape[1:]), device=real_x.device, dtype=torch.float32)
-        torch.cat([real_x.detach(), fake_x.detach()], out=xin[:2 * n])
-        alpha = get_mixing_factor(n) if mixing is None else mixing
-        ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha, out=xin[2 * n:])
-        x_hat = xin[2 * n:].detach().requires_grad_(True)
-        (scores, pred_hat), _, _ = dis(ops.Parts([xin[:2 * n], x_hat], [2, 1]))
-        g = calc_grad(x_hat, pred_hat).view(n, -1)
-        return ops.wgan_gp_d_loss_stacked(scores, g, iwass_drift_epsilon, grad_lambda, iwass_target)
     if stack_real_fake:
         # one critic pass over [reals; fakes]: half the launches, twice the work per launch, and one
         # gradient contribution per weight instead of two.  The reference evaluates the two passes

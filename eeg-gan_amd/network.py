@@ -201,13 +201,10 @@ class Discriminator(nn.Module):
         return resample_signal(h, self.progression_scale_up[stage], self.progression_scale_down[stage])
 
     def forward(self, x, y=None):
-        """``x``: a batch (tensor or {'x': tensor}) -> (scores, features, {}); or ``ops.Parts`` (several
-        minibatches in lockstep, one launch per layer while their activations are adjacent in memory)
-        -> (list of scores, list of features, {})."""
+        """``x``: a batch (tensor or {'x': tensor}) -> (scores, features, {})."""
         if isinstance(x, dict):
             x = x["x"]
         _require(y is None, "conditional discrimination")
-        parts = isinstance(x, ops.Parts)
         d = self.depth
         h = self.blocks[-(d + 1)](x, True)
         if d > 0:
@@ -215,7 +212,7 @@ class Discriminator(nn.Module):
             if self.alpha < 1.0:
                 low = self.blocks[-d].from_rgb(self._shrink(x, d - 1))
                 alpha = self.alpha_dev if self.alpha_dev is not None else self.alpha
-                h = h.like([ops.blend(a, b, alpha) for a, b in zip(h.t, low.t)]) if parts else ops.blend(h, low, alpha)
+                h = ops.blend(h, low, alpha)
         for i in range(d, 0, -1):
             h = self.blocks[-i](h)
             if i > 1:
@@ -223,6 +220,4 @@ class Discriminator(nn.Module):
         o = self.linear(h)
         if o.shape[2] != 1:
             o = resample_signal(o, o.shape[2], 1)  # mean over time as an average pool
-        if parts:
-            return [t.reshape(t.shape[0]) for t in o.t], h.t, {}
         return o.reshape(o.shape[0]), h, {}

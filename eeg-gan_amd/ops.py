@@ -98,6 +98,15 @@ class FlipCache:
         self.used = False  # only views that some input-gradient launch has asked for are kept up to date
         FlipCache._all.add(self)
 
+    def __deepcopy__(self, memo):
+        # the copy follows the COPIED parameter and starts without a view (a cloned view would carry the
+        # source's tag and never be found stale by the registry)
+        import copy
+        return FlipCache(copy.deepcopy(self.param, memo))
+
+    def __reduce__(self):
+        return (FlipCache, (self.param,))
+
     def _current_tag(self):
         p = self.param
         return (p.data_ptr(), p._version, _weights_epoch)
@@ -109,7 +118,12 @@ class FlipCache:
         self.used = True
         if self._stale():
             dev = self.param.device
-            todo = [c for c in FlipCache._all if c.used and c.param.device == dev and c.param.is_cuda and c._stale()]
+            # a cache made by copy.deepcopy or unpickling never ran __init__: (re-)register it, and always
+            # rebuild the view that was asked for, whatever the registry holds
+            FlipCache._all.add(self)
+            todo = [c for c in FlipCache._all if c is not self and c.used and c.param.device == dev
+                    and c.param.is_cuda and c._stale()]
+            todo.insert(0, self)
             table = (_FlipDesc * len(todo))()
             for i, c in enumerate(todo):
                 p = c.param
@@ -248,6 +262,10 @@ class _DirectGrads:
         self.pending = {}   # kernel variant -> [(job, tensors it reads, parameters)] not yet submitted
         self.queued = False
 
+    def reset(self):
+        """Forget everything queued: a backward pass that raised never ran ``finish``."""
+        self.touched, self.keep, self.jobs, self.pending, self.queued = {}, [], [], {}, False
+
     def usable(self, w):
         return self.enabled and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.is_cuda
 
@@ -333,7 +351,7 @@ class _DirectGrads:
             for p, _ in self.touched.values():
                 p.grad = p._eeggan_grad
         finally:
-            self.touched, self.keep, self.jobs, self.pending, self.queued = {}, [], [], {}, False
+            self.reset()
 
 
 _direct = _DirectGrads()
@@ -379,9 +397,16 @@ def conv1d_wgrad_group_raw(jobs):
 
 @contextlib.contextmanager
 def direct_weight_grads(enabled=True):
+    if _direct.queued:
+        # left over from a backward pass that raised after queueing work (the engine then never ran the
+        # end-of-backward callback): without this every later pass would skip registering it
+        _direct.reset()
     prev, _direct.enabled = _direct.enabled, bool(enabled)
     try:
         yield
+    except BaseException:
+        _direct.reset()
+        raise
     finally:
         _direct.enabled = prev
 
@@ -535,177 +560,6 @@ class _Conv(Function):
 def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None):
     """Fused equalized conv layer of the discriminator path (twice differentiable)."""
     return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip)
-
-
-# --------------------------------------------------------------------------------------- lockstep passes
-# Several independent minibatches can go through the critic in lockstep ("parts": e.g. the stacked
-# reals+fakes and the gradient-penalty interpolates, which need autograd graphs of their own because
-# only the latter is differentiated twice).  While the parts of an activation lie back to back in ONE
-# allocation, a layer runs ONE launch over all of them and hands out views; each part still has its
-# own place in the autograd graph: a backward call that gets the gradient of only one part (the
-# penalty's first-order pass) works on that part alone, the end-of-iteration backward, which gets all
-# of them, again runs one launch over the union.
-class Parts:
-    """Minibatches in lockstep: ``t`` the tensors, ``segments`` how many independent minibatches each
-    one stacks (MinibatchStddev statistics stay inside a minibatch)."""
-
-    def __init__(self, tensors, segments=None):
-        self.t = list(tensors)
-        self.segments = list(segments) if segments is not None else [1] * len(self.t)
-
-    def like(self, tensors):
-        return Parts(tensors, self.segments)
-
-    @property
-    def shape(self):  # of the first part: the parts agree in everything but the batch
-        return self.t[0].shape
-
-    @property
-    def device(self):
-        return self.t[0].device
-
-
-def _union(ts):
-    """One tensor over the memory of ``ts`` if they lie back to back in one allocation (contiguous
-    float32, equal trailing shapes), else None."""
-    if any(t is None for t in ts):
-        return None
-    t0 = ts[0]
-    if len(ts) == 1:
-        return t0 if t0.is_contiguous() else None
-    base = t0.untyped_storage().data_ptr()
-    off, rows = t0.storage_offset(), 0
-    for t in ts:
-        if (not t.is_contiguous() or t.dtype != torch.float32 or t.shape[1:] != t0.shape[1:]
-                or t.untyped_storage().data_ptr() != base or t.storage_offset() != off):
-            return None
-        off += t.numel()
-        rows += t.shape[0]
-    return t0.detach().as_strided((rows,) + tuple(t0.shape[1:]), t0.stride())
-
-
-def _split(t, like):
-    return list(torch.split(t, [p.shape[0] for p in like]))
-
-
-class _ConvParts(Function):
-    """``_Conv`` for parts in lockstep (same weights, one launch while the parts are adjacent in memory)."""
-
-    @staticmethod
-    def forward(ctx, w, bias, in_scale, act, slope, flip, n, *xd):
-        if act not in (ACT_NONE, ACT_LRELU):
-            raise ValueError("_ConvParts supports linear and leaky-relu epilogues")
-        xs, drops = [_chk(x, "conv x") for x in xd[:n]], list(xd[n:])
-        has_drop = drops[0] is not None
-        if act == ACT_NONE and has_drop:
-            raise ValueError("a drop multiplier needs the leaky-relu epilogue")
-        xu = _union(xs)
-        du = _union(drops) if has_drop else None
-        if xu is not None and (du is not None or not has_drop):
-            ys = _split(conv1d_raw(xu, w, bias, du, in_scale=in_scale, act=act, act_param=slope), xs)
-        else:
-            ys = [conv1d_raw(x, w, bias, d, in_scale=in_scale, act=act, act_param=slope) for x, d in zip(xs, drops)]
-        ctx.n, ctx.flip, ctx.in_scale, ctx.slope, ctx.has_bias = n, flip, in_scale, slope, bias is not None
-        ctx.masked = act == ACT_LRELU
-        ctx.save_for_backward(w, bias, *xs, *drops, *(ys if ctx.masked else []))
-        return tuple(ys)
-
-    @staticmethod
-    def backward(ctx, *gys):
-        n = ctx.n
-        saved = ctx.saved_tensors
-        w, bias = saved[0], saved[1]
-        xs, drops = list(saved[2:2 + n]), list(saved[2 + n:2 + 2 * n])
-        ys = [y.detach() for y in saved[2 + 2 * n:2 + 3 * n]] if ctx.masked else [None] * n  # (as in _Conv)
-        gys = [None if g is None else _chk(g, "conv grad") for g in gys]
-        live = [i for i in range(n) if gys[i] is not None]
-        need_x = [ctx.needs_input_grad[7 + i] for i in range(n)]
-        want_w = (ctx.needs_input_grad[0] or (ctx.has_bias and ctx.needs_input_grad[1])) and not _input_grad_only
-        direct = _direct.usable(w) and (bias is None or _direct.usable(bias))
-        gxs, gw, gb = [None] * n, None, None
-        joint = (not torch.is_grad_enabled() and len(live) == n and n > 1 and (direct or not want_w)
-                 and all(need_x[i] == need_x[0] for i in range(n)))
-        xu = yu = du = None
-        if joint:  # the saved operands must be adjacent, the gradients are made so below
-            xu, du = _union(xs), (_union(drops) if drops[0] is not None else None)
-            yu = _union(ys) if ctx.masked else None
-            joint = (xu is not None and (du is not None or drops[0] is None) and (yu is not None or not ctx.masked))
-        if joint:
-            gyu = _union(gys)
-            if need_x[0]:
-                if gyu is not None:
-                    gxs = _split(conv1d_raw(gyu, w, None, None, in_scale=ctx.in_scale, transposed=True, mask_y=yu,
-                                            mask_drop=du, mask_slope=ctx.slope, flip=ctx.flip), xs)
-                else:  # gradients arrive apart: one launch per part, into one buffer, adjacent from here on
-                    gxs = _split(torch.empty_like(xu), xs)
-                    for i in range(n):
-                        conv1d_raw(gys[i], w, None, None, in_scale=ctx.in_scale, transposed=True, mask_y=ys[i],
-                                   mask_drop=drops[i], mask_slope=ctx.slope, flip=ctx.flip, out=gxs[i])
-            if want_w:
-                if gyu is not None:
-                    _direct.wgrad(w, bias, xu, gyu, ctx.in_scale, yu, du, ctx.slope)
-                else:
-                    for i in range(n):
-                        _direct.wgrad(w, bias, xs[i], gys[i], ctx.in_scale, ys[i], drops[i], ctx.slope)
-        else:
-            for i in live:
-                if need_x[i]:
-                    gxs[i] = _ConvT.apply(gys[i], w, ys[i], drops[i], ctx.in_scale, ctx.slope, ctx.flip)
-                if want_w:
-                    if direct:
-                        _direct.wgrad(w, bias, xs[i], gys[i], ctx.in_scale, ys[i], drops[i], ctx.slope)
-                    else:
-                        pw, pb = _WGrad.apply(xs[i], gys[i], w.shape[2], ctx.in_scale, ctx.has_bias, ys[i], drops[i],
-                                              ctx.slope)
-                        gw = pw if gw is None else gw + pw
-                        if pb is not None:
-                            gb = pb if gb is None else gb + pb
-        return (gw, gb, None, None, None, None, None, *gxs, *([None] * n))
-
-
-def conv1d_parts(xs, w, bias, drops, in_scale, act, slope=0.0, flip=None):
-    """``conv1d`` for parts in lockstep; returns the list of outputs."""
-    n = len(xs)
-    return list(_ConvParts.apply(w, bias, float(in_scale), int(act), float(slope), flip, n, *xs, *drops))
-
-
-class _GatherParts(Function):
-    """``_Gather`` (the resampler) for parts in lockstep."""
-
-    @staticmethod
-    def forward(ctx, fwd, bwd, *xs):
-        xs = [_chk(x, "resample x") for x in xs]
-        ctx.tables = (fwd, bwd)
-        xu = _union(xs)
-        if xu is not None:
-            return tuple(_split(_gather_raw(xu, fwd), xs))
-        return tuple(_gather_raw(x, fwd) for x in xs)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        fwd, bwd = ctx.tables
-        n = len(gs)
-        need = [ctx.needs_input_grad[2 + i] for i in range(n)]
-        out = [None] * n
-        if not torch.is_grad_enabled() and n > 1 and all(g is not None for g in gs) and all(need):
-            gs = [_chk(g, "resample grad") for g in gs]
-            gu = _union(gs)
-            if gu is not None:
-                return (None, None, *_split(_gather_raw(gu, bwd), gs))
-            rows = sum(g.shape[0] for g in gs)
-            buf = torch.empty((rows,) + tuple(gs[0].shape[1:-1]) + (bwd[3],), device=gs[0].device, dtype=torch.float32)
-            out = _split(buf, gs)
-            for g, o in zip(gs, out):
-                _gather_raw(g, bwd, out=o)
-            return (None, None, *out)
-        for i, g in enumerate(gs):
-            if g is not None and need[i]:
-                out[i] = _Gather.apply(g, bwd, fwd)
-        return (None, None, *out)
-
-
-def gather_parts(xs, fwd, bwd):
-    return list(_GatherParts.apply(fwd, bwd, *xs))
 
 
 # --------------------------------------------------------------------------------------- D tail
@@ -888,6 +742,32 @@ class _GLayer(Function):
 
 def g_layer(x, w, bias, drop, in_scale, slope, mode="pn", kind="same", tanh_scale=0.5, flip=None):
     return _GLayer.apply(x, w, bias, drop, float(in_scale), float(slope), mode, kind, float(tanh_scale), flip)
+
+
+class _ScaledTanh(Function):
+    """y = tanh(scale * x) on its own (on the training path the to_rgb conv applies it as its epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _chk(x, "scaled tanh x")
+        y = torch.empty_like(x)
+        call("eeggan_scaled_tanh", x.data_ptr(), y.data_ptr(), x.numel(), float(scale), _stream())
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = _chk(gy, "scaled tanh grad")
+        gc = torch.empty_like(y)
+        call("eeggan_tanh_bwd", gy.data_ptr(), y.data_ptr(), gc.data_ptr(), y.numel(), float(ctx.scale), _stream())
+        return gc, None
+
+
+def scaled_tanh(x, scale):
+    return _ScaledTanh.apply(x, float(scale))
 
 
 class _PixelNorm(Function):

@@ -63,12 +63,6 @@ def resample_signal(signal, signal_freq, desired_freq, pytorch=True):
     Runs as one fused gather kernel; differentiable to any order (the op is linear)."""
     if not pytorch or isinstance(signal, np.ndarray):
         raise NotImplementedError("resample_signal: only device tensors are supported (pytorch=True)")
-    if isinstance(signal, ops.Parts):  # lockstep passes through the critic
-        ratio = Fraction(int(desired_freq), int(signal_freq))
-        if ratio == 1:
-            return signal
-        fwd, bwd = device_tables(signal.shape[2], ratio.numerator, ratio.denominator, signal.device)
-        return signal.like(ops.gather_parts(signal.t, fwd, bwd))
     if signal.dim() != 3:
         raise NotImplementedError("resample_signal: expected a [B, C, T] tensor")
     if isinstance(desired_freq, float) or isinstance(signal_freq, float):

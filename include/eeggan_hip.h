@@ -159,6 +159,9 @@ int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, float* y, float
  * slope = 1 gives the backward of PixelNorm->GDrop alone. */
 int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop, const float* d,
                               float* gc, int B, int C, int T, float slope, void* stream);
+/* y = tanh(scale * x): ScaledTanh.forward on its own (layers.py:17-23); on the training path it is the
+ * epilogue of the to_rgb conv (EEGGAN_ACT_TANH). */
+int eeggan_scaled_tanh(const float* x, float* y, size_t n, float scale, void* stream);
 /* gc = gy * scale * (1 - y^2): backward of y = tanh(scale*c) (layers.py:17-23). */
 int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_t n, float scale, void* stream);
 /* out = ca*a + cb*b (b may be NULL: out = ca*a).  Fade-in blends network.py:393-396,533-540. */

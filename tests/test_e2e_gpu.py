@@ -23,8 +23,8 @@ pytestmark = pytest.mark.gpu
 # The reference's fp32 run is ONE draw of the rounding noise of an ill-conditioned gradient; another
 # fp32 implementation (different summation order) is another draw.  A tensor passes when its
 # deviation stays within NOISE_FACTOR x the reference's own fp32-vs-fp64 deviation (floor 1e-4).
-# Largest ratio measured on the five fixtures: ~3.
-NOISE_FACTOR = 4.0
+# Largest ratio measured on the five fixtures: 0.8 (per term), see the printed "worst deviation" lines.
+NOISE_FACTOR = 2.0
 
 E2E = ["e2e_d0_a1", "e2e_d1_a05", "e2e_d4_a1", "e2e_d7_a1", "e2e_d7_a05"]
 
@@ -67,6 +67,7 @@ def _check_grads(fx, key, module, floor=1e-4):
 # systematic kernel error is not excused by this: on a well-conditioned tensor the response to 1e-5
 # noise stays near 1e-5.
 COND_EPS, COND_TRIALS = 1e-5, 4
+COND_CAP = 5e-3  # the measured conditioning never excuses more than this
 
 
 def _term_grads(d, g, real, z, mix, seed, jitter=lambda t: t):
@@ -107,7 +108,8 @@ def _check_d_terms(fx, g, d, real, z, mix, seed):
         for term in base:
             for k, a, b in zip(names, base[term], pert[term]):
                 if a is not None and float(a.norm()) > 0.0:
-                    cond[k] = max(cond[k], float((a - b).norm()) / float(a.norm()))
+                    cond[k] = min(COND_CAP, max(cond[k], float((a - b).norm()) / float(a.norm())))
+    worst = (0.0, "")
     for term, grads in base.items():
         for k, gr in zip(names, grads):
             key = f"d_term_{term}_sub.{k}"
@@ -128,6 +130,8 @@ def _check_d_terms(fx, g, d, real, z, mix, seed):
             assert min(e64, e32) < tol, (f"critic term '{term}', {k}: differs by {e64:.3e} (fp64 ref) / {e32:.3e} "
                                          f"(fp32 ref), tolerance {tol:.3e} (reference noise {noise:.1e}, "
                                          f"conditioning {cond[k]:.1e})")
+            worst = max(worst, (min(e64, e32) / max(noise, 2.5e-5), f"{term}.{k}"))
+    print(f"critic terms: worst deviation = {worst[0]:.2f} x the reference's own fp32-vs-fp64 distance ({worst[1]})")
     return cond
 
 
@@ -198,6 +202,50 @@ def ops_mean_neg(v):
     return ops.mean_scale(v, -1.0)
 
 
+def _oracle_gate(name, got, ref64, ref32, worst, scale=None, cond=0.0):
+    """Gate for a gradient checked against the oracle run on this machine in BOTH precisions: the fp32 oracle
+    run is one draw of the rounding noise of this gradient (LeakyReLU mask flips, see above), so the tensor
+    must lie within max(1e-4, NOISE_FACTOR x |ref32 - ref64|) of the fp64 run or of the fp32 run.  ``scale``:
+    norm the deviations are measured against (default: the gradient's own; the critic's summed gradient
+    uses the sum of its terms' norms, because the real and fake terms cancel in it -- completely for the
+    output layer's bias, where only the drift term survives).  ``cond``: this tensor's measured response (on
+    the same scale) to 1e-5 relative noise on the critic's inputs: the size of the jumps single LeakyReLU
+    mask flips cause in it, which one fp32 oracle draw may or may not have met (taken NOISE_FACTOR times like
+    the oracle's own distance, and capped at COND_CAP)."""
+    def dev(a, b):
+        a = torch.as_tensor(a).detach().double().cpu().flatten()
+        b = torch.as_tensor(b).detach().double().cpu().flatten()
+        return float((a - b).norm()) / (float(b.norm()) if scale is None else scale)
+
+    noise = dev(ref32, ref64)
+    tol = max(1e-4, NOISE_FACTOR * noise, min(NOISE_FACTOR * cond, COND_CAP))
+    e64, e32 = dev(got, ref64), dev(got, ref32)
+    e = min(e64, e32)
+    assert e < tol, (f"{name}: differs by {e64:.3e} (fp64 oracle) / {e32:.3e} (fp32 oracle), tolerance {tol:.3e} "
+                     f"(oracle fp32-vs-fp64 {noise:.1e}, conditioning {cond:.1e})")
+    return max(worst, (e / max(noise, 2.5e-5), name))
+
+
+def _oracle_d_grads(O, dp, ds, gp, gs, real, z, mix, depth, alpha, dtype, src=None, term_scales=False):
+    """(loss, gradients per critic parameter[, scale per parameter]) of one critic iteration of the oracle in
+    ``dtype``.  The scale of a parameter is the sum of the norms of its summed gradient and of the gradients
+    of the two score terms (-mean D(real), mean D(fake)) that cancel inside it."""
+    cast = lambda prm: {k: v.detach().to(dtype).requires_grad_(True) for k, v in prm.items()}
+    dpc, gpc = cast(dp), cast(gp)
+    src = src or O.DropSource("off")
+    loss, aux = O.d_loss_wgan_gp(dpc, ds, gpc, gs, real.to(dtype), z.to(dtype), depth, alpha, O.NetConfig(),
+                                 mix.to(dtype), src, src)
+    params = list(dpc.values())
+    grads = torch.autograd.grad(loss, params, allow_unused=True, retain_graph=term_scales)
+    if not term_scales:
+        return loss.detach(), grads
+    g_real = torch.autograd.grad(aux["d_real"].mean(), params, allow_unused=True, retain_graph=True)
+    g_fake = torch.autograd.grad(aux["d_fake"].mean(), params, allow_unused=True)
+    norm = lambda t: 0.0 if t is None else float(t.norm())
+    scales = [norm(a) + norm(b) + norm(c) for a, b, c in zip(grads, g_real, g_fake)]
+    return loss.detach(), grads, scales
+
+
 def test_blocks_against_reference_fixture(dev):
     """One GBlock / DBlock at a time (reference network.py:206-218, 441-449) with the reference's GDrop
     draws: head block, a block with to_rgb, a wide block; first block with from_rgb, a middle block, the
@@ -230,20 +278,18 @@ def test_against_oracle_other_config(dev):
     g, d = _build(dev, depth, alpha, 5)
     gp, gs = oracle_params(g)
     dp, ds = oracle_params(d)
-    for p in list(gp.values()) + list(dp.values()):
-        p.requires_grad_(True)
     T = config.seq_len(depth)
     rng = np.random.default_rng(seed)
     real = torch.from_numpy(O.synthetic_eeg(B, 5, T, rng))
     gen = torch.Generator().manual_seed(seed)
     z = torch.randn(B, 256, generator=gen)
     mix = torch.rand(B, 1, 1, generator=gen)
-    cfg = O.NetConfig()
     np.random.seed(seed)
-    src = O.DropSource("numpy")
-    loss_ref, aux = O.d_loss_wgan_gp(dp, ds, gp, gs, real.double(), z.double(), depth, alpha, cfg, mix.double(), src,
-                                     src)
-    grads_ref = torch.autograd.grad(loss_ref, list(dp.values()), allow_unused=True)
+    loss_ref, grads_ref, scales = _oracle_d_grads(O, dp, ds, gp, gs, real, z, mix, depth, alpha, torch.float64,
+                                                  O.DropSource("numpy"), term_scales=True)
+    np.random.seed(seed)
+    _, grads_ref32 = _oracle_d_grads(O, dp, ds, gp, gs, real, z, mix, depth, alpha, torch.float32,
+                                     O.DropSource("numpy"))
 
     g, d = g.to(dev), d.to(dev)
     g.depth = d.depth = depth
@@ -253,11 +299,13 @@ def test_against_oracle_other_config(dev):
                                      mixing=mix.to(dev))
     loss.backward()
     assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
-    for (k, p), gr in zip(d.named_parameters(), grads_ref):
+    worst = (0.0, "")
+    for (k, p), gr, gr32, sc in zip(d.named_parameters(), grads_ref, grads_ref32, scales):
         if gr is None:
             assert p.grad is None, k
         else:
-            assert rel(p.grad, gr) < 2e-3, (k, rel(p.grad, gr))  # fp32 noise floor of these gradients
+            worst = _oracle_gate(k, p.grad, gr, gr32, worst, sc)
+    print(f"depth 3, alpha 0.7: worst deviation = {worst[0]:.2f} x the oracle's fp32-vs-fp64 distance ({worst[1]})")
 
 
 def test_headline_configuration_against_oracle(dev):
@@ -265,16 +313,15 @@ def test_headline_configuration_against_oracle(dev):
     iteration against the fp64 oracle run here, with the weight gradients taken the way the trainers take
     them (deposited directly, submitted in groups).  Every kernel runs in its production shape: one unit
     per wave in the weight-stationary conv, the reduction-split tile on the short wide layers, grouped
-    weight gradients with ~16 splits per layer.  Loss to 1e-4; gradients to 2e-3 per tensor (the LeakyReLU
-    mask flips described above; measured: worst tensor 1.3e-3)."""
+    weight gradients with ~16 splits per layer.  Loss to 1e-4; gradients per tensor within
+    max(1e-4, NOISE_FACTOR x the oracle's own fp32-vs-fp64 distance for that tensor, the tensor's measured and
+    capped conditioning) of either oracle run."""
     from eeggan_amd import config, losses, ops
     from oracle import ref_cpu as O
     depth, alpha, B, seed = 7, 1.0, 32, 1373
     g, d = _build(dev, depth, alpha, 5)
     gp, gs = oracle_params(g)
     dp, ds = oracle_params(d)
-    for p in list(gp.values()) + list(dp.values()):
-        p.requires_grad_(True)
     T = config.seq_len(depth)
     rng = np.random.default_rng(seed)
     real = torch.from_numpy(O.synthetic_eeg(B, 5, T, rng))
@@ -282,29 +329,161 @@ def test_headline_configuration_against_oracle(dev):
     z = torch.randn(B, 256, generator=gen)
     mix = torch.rand(B, 1, 1, generator=gen)
     np.random.seed(seed)
-    src = O.DropSource("numpy")
-    loss_ref, _ = O.d_loss_wgan_gp(dp, ds, gp, gs, real.double(), z.double(), depth, alpha, O.NetConfig(), mix.double(),
-                                   src, src)
-    grads_ref = torch.autograd.grad(loss_ref, list(dp.values()), allow_unused=True)
+    loss_ref, grads_ref, scales = _oracle_d_grads(O, dp, ds, gp, gs, real, z, mix, depth, alpha, torch.float64,
+                                                  O.DropSource("numpy"), term_scales=True)
+    np.random.seed(seed)
+    _, grads_ref32 = _oracle_d_grads(O, dp, ds, gp, gs, real, z, mix, depth, alpha, torch.float32,
+                                     O.DropSource("numpy"))
 
     g, d = g.to(dev), d.to(dev)
     g.depth = d.depth = depth
     g.alpha = d.alpha = alpha
-    np.random.seed(seed)
-    loss = losses.discriminator_loss(d, g, {"x": real.to(dev)}, {"z": z.to(dev)}, "wgan_gp", 1e-3, 10.0, 1.0,
-                                     mixing=mix.to(dev))
-    with ops.direct_weight_grads():
-        loss.backward()
-    assert abs(float(loss.detach()) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
-    worst = 0.0
-    for (k, p), gr in zip(d.named_parameters(), grads_ref):
+
+    def run(real_d):
+        np.random.seed(seed)
+        loss = losses.discriminator_loss(d, g, {"x": real_d}, {"z": z.to(dev)}, "wgan_gp", 1e-3, 10.0, 1.0,
+                                         mixing=mix.to(dev))
+        with ops.direct_weight_grads():
+            loss.backward()
+        return loss.detach(), [None if p.grad is None else p.grad.clone() for p in d.parameters()]
+
+    loss, grads = run(real.to(dev))
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    # conditioning: the response of every gradient to COND_EPS relative noise on the reals
+    cond = [0.0] * len(grads)
+    jit = torch.Generator(device=dev).manual_seed(seed)
+    for _ in range(COND_TRIALS):
+        rd = real.to(dev)
+        _, pert = run(rd * (1.0 + COND_EPS * torch.randn(rd.shape, device=dev, generator=jit)))
+        for i, (a, b) in enumerate(zip(grads, pert)):
+            if a is not None:
+                cond[i] = max(cond[i], float((a - b).norm()) / scales[i])
+    worst = (0.0, "")
+    for (k, p), got, gr, gr32, sc, cd in zip(d.named_parameters(), grads, grads_ref, grads_ref32, scales, cond):
         if gr is None:
-            assert p.grad is None, k
+            assert got is None, k
         else:
-            e = rel(p.grad, gr)
-            worst = max(worst, e)
-            assert e < 2e-3, (k, e)
-    print(f"headline configuration: worst gradient deviation {worst:.2e}")
+            worst = _oracle_gate(k, got, gr, gr32, worst, sc, cd)
+    print(f"headline configuration: worst deviation = {worst[0]:.2f} x the oracle's fp32-vs-fp64 distance ({worst[1]})")
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_benchmarked_launch_path_against_oracle(dev, alpha):
+    """The launch path ``bench.py`` times, at the configuration it times (final stage, T = 1920, 32 samples;
+    alpha 1 and mid-transition): ``GraphedTrainer`` with device-side noise handling, i.e. ONE stacked critic
+    pass over [reals; fakes] (64 samples), ONE generator pass over the latents of all five critic iterations
+    (160 samples), weight gradients deposited directly in groups, Adam inside the graphs, every iteration a
+    graph replay -- against the fp64 oracle's five critic iterations and generator iteration
+    (reference losses.py:73-120, 40-48; trainer.py:79-96).  GDrop strength is 0 so that both sides see the
+    same multipliers, the mixing factors are fixed, and lr = 0 keeps the weights in place, so with beta1 = 0
+    Adam's first moment IS the last iteration's gradient and its second moment the decayed sum of squares of
+    all five.  Losses to 1e-4; gradients per tensor within max(1e-4, NOISE_FACTOR x the oracle's own
+    fp32-vs-fp64 distance, the tensor's measured and capped conditioning) of either oracle precision; second
+    moments to 4x that."""
+    from eeggan_amd import config, layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.layers import GDropLayer
+    from eeggan_amd.optim import Adam
+    from oracle import ref_cpu as O
+    depth, B, seed, repeats = 7, 32, 1373, 5
+    T = config.seq_len(depth)
+    rng = np.random.default_rng(seed)
+    reals = [torch.from_numpy(O.synthetic_eeg(B, 5, T, rng)) for _ in range(repeats)]
+    gen = torch.Generator().manual_seed(seed)
+    zs = [torch.randn(B, 256, generator=gen) for _ in range(repeats + 1)]
+    mix = torch.rand(B, 1, 1, generator=gen)
+    g, d = config.build_models(5)
+    gp, gs = oracle_params(g)
+    dp, ds = oracle_params(d)
+    layers.set_drop_mode("device")
+    try:
+        g, d = g.to(dev), d.to(dev)
+        g.depth = d.depth = depth
+        g.alpha = d.alpha = alpha
+        for m in list(g.modules()) + list(d.modules()):
+            if isinstance(m, GDropLayer):
+                m.strength = 0
+        opt_g = Adam(g.parameters(), 0.0, **config.ADAM)
+        opt_d = Adam(d.parameters(), 0.0, **config.ADAM)
+        d_loss_fn, g_loss_fn = config.loss_closures()
+        mixd = mix.to(dev)
+
+        class _DS:
+            model_depth = depth
+
+        tr = GraphedTrainer(d, g, lambda dis, ge, r, z, **kw: d_loss_fn(dis, ge, r, z, mixing=mixd, **kw), g_loss_fn,
+                            _DS(), iter([{"z": z.to(dev)} for z in zs]), 0, opt_g, opt_d, d_training_repeats=repeats)
+        tr.dataiter = iter([{"x": r.to(dev)} for r in reals])
+        tr.train()
+        torch.cuda.synchronize()
+        assert tr._fakes_call is not None and tr._zall.shape[0] == repeats * B, "one generator pass per step"
+        d_loss, g_loss = float(tr._d_parts[0].out), float(tr._g_parts[0].out)
+        moments = lambda net, opt: [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                                    if p in opt.state else None for p in net.parameters()]
+        d_mom, g_mom = moments(d, opt_d), moments(g, opt_g)
+        # conditioning: replay the same step with COND_EPS relative noise on reals and latents (lr = 0 and
+        # beta1 = 0: the first moments afterwards are the last gradients of the jittered step)
+        jit = torch.Generator(device=dev).manual_seed(seed)
+        noisy = lambda t: t.to(dev) * (1.0 + COND_EPS * torch.randn(t.shape, device=dev, generator=jit))
+        d_cond, g_cond = [0.0] * len(d_mom), [0.0] * len(g_mom)
+        for _ in range(COND_TRIALS):
+            tr.dataiter = iter([{"x": noisy(r)} for r in reals])
+            tr.random_latents_generator = iter([{"z": noisy(z)} for z in zs])
+            tr.train()
+            torch.cuda.synchronize()
+            for cond, base, net, opt in ((d_cond, d_mom, d, opt_d), (g_cond, g_mom, g, opt_g)):
+                for i, p in enumerate(net.parameters()):
+                    if base[i] is not None:
+                        cond[i] = max(cond[i], float((opt.state[p]["exp_avg"] - base[i][0]).norm()))
+    finally:
+        layers.set_drop_mode("numpy")
+
+    # oracle: the five critic iterations in fp64 (weights never move: lr = 0), the last one in fp32 too
+    per_iter = [_oracle_d_grads(O, dp, ds, gp, gs, reals[i], zs[i], mix, depth, alpha, torch.float64,
+                                term_scales=(i == repeats - 1)) for i in range(repeats)]
+    scales = per_iter[-1][2]
+    _, last32 = _oracle_d_grads(O, dp, ds, gp, gs, reals[-1], zs[-1], mix, depth, alpha, torch.float32)
+    loss_ref = float(per_iter[-1][0])
+    assert abs(d_loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (d_loss, loss_ref)
+    worst = (0.0, "")
+    for i, (k, p) in enumerate(d.named_parameters()):
+        gr = per_iter[-1][1][i]
+        if gr is None:
+            assert p not in opt_d.state or float(opt_d.state[p]["exp_avg"].abs().max()) == 0.0, k
+            continue
+        m, v = d_mom[i]
+        assert float(opt_d.state[p]["step"]) == repeats * (1 + COND_TRIALS), k
+        cd = d_cond[i] / scales[i]
+        worst = _oracle_gate(f"D.{k}", m, gr, last32[i], worst, scales[i], cd)
+        # second moment: squares of the five gradients; a deviation e of a gradient (on the scale above)
+        # moves it by 2 e |g| scale, so it is held to 4x the gradient's tolerance on the squared scale
+        v_ref = sum(0.01 * 0.99 ** (repeats - 1 - j) * per_iter[j][1][i] ** 2 for j in range(repeats))
+        noise = float((last32[i].double() - gr).norm()) / scales[i]
+        tol_v = 4 * max(1e-4, NOISE_FACTOR * noise, min(NOISE_FACTOR * cd, COND_CAP))
+        v_scale = sum(0.01 * 0.99 ** (repeats - 1 - j) for j in range(repeats)) * scales[i] * float(gr.abs().max())
+        err_v = float((v.double().cpu() - v_ref).norm())
+        assert err_v < tol_v * v_scale, (k, err_v / v_scale, tol_v)
+
+    def g_grads(dtype):
+        cast = lambda prm, grad: {k: v.detach().to(dtype).requires_grad_(grad) for k, v in prm.items()}
+        gpc, dpc = cast(gp, True), cast(dp, False)
+        off = O.DropSource("off")
+        loss, _ = O.g_loss_wgan(dpc, ds, gpc, gs, zs[-1].to(dtype), depth, alpha, O.NetConfig(), off, off)
+        return loss.detach(), torch.autograd.grad(loss, list(gpc.values()), allow_unused=True)
+
+    gl64, gg64 = g_grads(torch.float64)
+    _, gg32 = g_grads(torch.float32)
+    assert abs(g_loss - float(gl64)) < 1e-4 * max(1.0, abs(float(gl64))), (g_loss, float(gl64))
+    for i, (k, p) in enumerate(g.named_parameters()):
+        if gg64[i] is None:
+            assert p not in opt_g.state or float(opt_g.state[p]["exp_avg"].abs().max()) == 0.0, k
+            continue
+        assert float(opt_g.state[p]["step"]) == 1.0 + COND_TRIALS, k
+        worst = _oracle_gate(f"G.{k}", g_mom[i][0], gg64[i], gg32[i], worst, None,
+                             g_cond[i] / max(float(gg64[i].norm()), 1e-300))
+    print(f"benchmarked path, alpha {alpha:g}: d_loss {d_loss:.6f} (oracle {loss_ref:.6f}), g_loss {g_loss:.6f} "
+          f"(oracle {float(gl64):.6f}); worst gradient deviation = {worst[0]:.2f} x the oracle's fp32-vs-fp64 "
+          f"distance ({worst[1]})")
 
 
 def test_full_step_fixture(dev):
@@ -540,11 +719,10 @@ def test_stacked_critic_pass_equals_sequential(dev):
             m.strength = 0
     d_loss_fn, _ = config.loss_closures()
     out = []
-    # sequential passes; reals+fakes stacked; stacked and the penalty's pass in lockstep -- the last one
-    # both with weight gradients accumulated by autograd and deposited directly (the trainers' mode)
-    for stacked, lockstep, direct in ((False, False, False), (True, False, False), (True, True, False),
-                                      (True, True, True)):
-        loss = d_loss_fn(d, g, {"x": real}, {"z": z}, mixing=mix, stack_real_fake=stacked, lockstep_penalty=lockstep)
+    # sequential passes; reals+fakes stacked, with weight gradients accumulated by autograd and deposited
+    # directly (the trainers' mode)
+    for stacked, direct in ((False, False), (True, False), (True, True)):
+        loss = d_loss_fn(d, g, {"x": real}, {"z": z}, mixing=mix, stack_real_fake=stacked)
         with ops.direct_weight_grads(direct):
             loss.backward()
         out.append((float(loss.detach()), {k: p.grad.clone() for k, p in d.named_parameters() if p.grad is not None}))
@@ -552,10 +730,8 @@ def test_stacked_critic_pass_equals_sequential(dev):
     d.zero_grad()
     ops.mean_scale(d({"x": real})[0], -1.0).backward()
     term = {k: float(p.grad.norm()) for k, p in d.named_parameters() if p.grad is not None}
-    for what, (l1, g1) in zip(("stacked", "lockstep", "lockstep, direct gradients"), out[1:]):
-        # (in lockstep the interpolates' pass runs other tile shapes too, so the PENALTY meets the mask flips
-        # described above: the gradient norms it is built from jump by ~1e-3 of one sample's norm per flip)
-        assert abs(l0 - l1) < (1e-5 if what == "stacked" else 1e-4) * max(1.0, abs(l0)), what
+    for what, (l1, g1) in zip(("stacked", "stacked, direct gradients"), out[1:]):
+        assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), what
         assert g0.keys() == g1.keys() and len(g0) > 0, what
         for k in g0:
             e = float((g0[k] - g1[k]).norm()) / max(float(g0[k].norm()) + term[k], 1e-30)

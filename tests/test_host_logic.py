@@ -186,3 +186,37 @@ def test_trainer_plugin_schedule():
     tr.call_plugins("epoch", 1)
     tr.call_plugins("end", 1)  # nobody registered: no-op
     assert [(n, t) for n, t, _ in calls] == [("b/tick", 1)]
+
+
+def test_direct_gradient_queue_recovers_from_a_failed_backward():
+    """A backward pass that raises after queueing weight-gradient work never reaches the end-of-backward
+    callback; the next pass must start from an empty queue and register the callback again."""
+    from eeggan_amd import ops
+    d = ops._direct
+    d.queued, d.pending, d.jobs, d.touched, d.keep = True, {"stale": [1]}, [(0, None)], {1: [None, 1]}, [object()]
+    with ops.direct_weight_grads():
+        assert not d.queued and not d.pending and not d.jobs and not d.touched and not d.keep
+    # ... and an exception inside the context leaves nothing behind either
+    try:
+        with ops.direct_weight_grads():
+            d.queued, d.pending = True, {"x": [1]}
+            raise RuntimeError("backward failed")
+    except RuntimeError:
+        pass
+    assert not d.queued and not d.pending and not d.enabled
+
+
+def test_flip_cache_copy_follows_the_copied_parameter():
+    """copy.deepcopy of a layer (an EMA copy of a network) must give the copy a cache of its own that tracks
+    the COPIED weight and starts stale, and a cache that never ran __init__ must still register itself."""
+    import copy
+    import torch
+    from eeggan_amd import ops
+    from eeggan_amd.layers import EqualizedConv1d
+    conv = EqualizedConv1d(4, 6, 3, 1, False, True, "kaiming_normal", 0.2, True, 1, 1)
+    conv._flip.tag, conv._flip.wt = ("pretend", 0, 0), torch.zeros(4, 6, 3)
+    twin = copy.deepcopy(conv)
+    assert twin._flip is not conv._flip
+    assert twin._flip.param is twin.conv.weight and twin._flip.param is not conv.conv.weight
+    assert twin._flip.tag is None and twin._flip.wt is None and twin._flip in ops.FlipCache._all
+    assert twin._flip._stale()

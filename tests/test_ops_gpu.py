@@ -220,6 +220,33 @@ def test_conv_wgrad_grouped(dev):
     assert rel(one, single.double()) < 1e-6
 
 
+def test_direct_wgrad_solo_submission(dev):
+    """A layer that keeps the chip busy for >= 16 rounds by itself (here 140 samples of the 64 -> 64, T = 1920
+    layer) is not queued with others: its weight gradient is submitted alone, right away, and still lands
+    in the persistent gradient buffer at the end of the backward pass.  Against fp64."""
+    ops = _ops()
+    B, C, T, scale = 140, 64, 1920, 0.31
+    g = torch.Generator().manual_seed(140)
+    x = torch.randn(B, C, T, generator=g)
+    w = torch.randn(C, C, 3, generator=g)
+    b = torch.randn(C, generator=g)
+    drop = torch.rand(B, C, generator=g) + 0.5
+    gy = torch.randn(B, C, T, generator=g)
+    units = ((B * (T // 32) + 1) // 2)
+    assert units >= ops.WGRAD_SOLO_UNITS
+    wd = torch.nn.Parameter(w.to(dev))
+    bd = torch.nn.Parameter(b.to(dev))
+    y = ops.conv1d(x.to(dev), wd, bd, drop.to(dev), scale, 1, 0.2)
+    with ops.direct_weight_grads():
+        y.backward(gy.to(dev))
+    assert wd.grad is wd._eeggan_grad
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    yref = F.leaky_relu(F.conv1d(x.double() * scale, w64, b64, padding=1), 0.2) * drop.double()[:, :, None]
+    gw_ref, gb_ref = torch.autograd.grad(yref, [w64, b64], gy.double())
+    assert rel(wd.grad, gw_ref) < TOL and rel(bd.grad, gb_ref) < TOL
+
+
 def test_conv_rejects_bad_arguments(dev):
     ops = _ops()
     from eeggan_amd._lib import EegganError
@@ -466,6 +493,37 @@ def test_per_op_golden(dev):
         assert rel(resample_signal(t(f"rs_up{i}_x"), dn, up), fx[f"rs_up{i}_y"]) < 5e-5
         assert rel(resample_signal(t(f"rs_dn{i}_x"), up, dn), fx[f"rs_dn{i}_y"]) < 5e-5
     assert rel(ops.minibatch_stddev(t("mb_x"), 4), fx["mb_y"]) < TOL
+    # MinibatchStddev to second order: gradient, and the gradient of <gradient, v> w.r.t. both of its inputs
+    xd, gyd = t("mb_x").requires_grad_(True), t("mb_gy").requires_grad_(True)
+    (gx,) = torch.autograd.grad(ops.minibatch_stddev(xd, 4), xd, gyd, create_graph=True)
+    assert rel(gx, fx["mb_gx"]) < TOL
+    ggy, gxx = torch.autograd.grad(gx, [gyd, xd], t("mb_v"))
+    assert rel(ggy, fx["mb_ggy"]) < TOL and rel(gxx, fx["mb_gxx"]) < 5 * TOL
+    # pixel norm backward (drop absent, slope 1: the norm alone)
+    yd, dd = ops.pixelnorm_drop_fwd_raw(t("pn_h"), None)
+    assert rel(ops.pixelnorm_drop_bwd_raw(t("pn_gy"), yd, None, dd, 1.0), fx["pn_gh"]) < TOL
+    # a length-1 signal is repeated
+    assert rel(resample_signal(t("rs_rep_x"), 1, 4), fx["rs_rep_y"]) < 1e-7
+    # the full-length kernels: generator head (k = 32, pad = 31 on a length-1 signal) and critic tail (pad = 0)
+    from eeggan_amd._lib import call
+    st = torch.cuda.current_stream().cuda_stream
+    x, w, b, gy = t("conv_head_x"), t("conv_head_w"), t("conv_head_b"), t("conv_head_gy")
+    B, Cin = x.shape[0], x.shape[1]
+    Cout, _, KT = w.shape
+    sc = float(fx["conv_head_scale"])
+    y = torch.empty(B, Cout, KT, device=dev)
+    call("eeggan_head_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, Cin, Cout, KT, sc, 0, 0.0, st)
+    assert rel(y, fx["conv_head_y"]) < TOL
+    gz, gw, gb = torch.empty(B, Cin, device=dev), torch.empty_like(w), torch.empty(Cout, device=dev)
+    call("eeggan_head_dgrad", gy.data_ptr(), w.data_ptr(), gz.data_ptr(), B, Cin, Cout, KT, sc, st)
+    call("eeggan_head_wgrad", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, Cin, Cout, KT, sc, st)
+    assert rel(gz, fx["conv_head_gx"]) < TOL and rel(gw, fx["conv_head_gw"]) < TOL and rel(gb, fx["conv_head_gb"]) < TOL
+    x, w, b, gy = t("conv_tail_x"), t("conv_tail_w"), t("conv_tail_b"), t("conv_tail_gy")
+    sc = float(fx["conv_tail_scale"])
+    assert rel(ops._tail_fwd_raw(x, w, b, None, sc, 0, 0.0), fx["conv_tail_y"]) < TOL
+    assert rel(ops._tail_dgrad_raw(gy, w, sc), fx["conv_tail_gx"]) < TOL
+    gw, gb = ops._tail_wgrad_raw(x, gy, sc, True)
+    assert rel(gw, fx["conv_tail_gw"]) < TOL and rel(gb, fx["conv_tail_gb"]) < TOL
     y = ops.conv1d_raw(t("tanh_c"), torch.eye(5, device=dev)[:, :, None].contiguous(), None, None, act=2,
                        act_param=0.5)
     assert rel(y, fx["tanh_y"]) < TOL
@@ -516,3 +574,38 @@ def test_conv_pixelnorm_fused(dev, B, Cin, Cout, T):
     assert rel(d, dref) < TOL
     assert rel(y, h * dref[:, None, :] * drop.double()[:, :, None]) < TOL
     assert ops.conv1d_pixelnorm_raw(x[:2].to(dev), w.to(dev), None, None, in_scale=1.0, slope=0.2) is None  # too few subtiles
+
+
+def test_scaled_tanh_module(dev):
+    """ScaledTanh on its own (reference layers.py:17-23): tanh(scale * x), with its gradient."""
+    from eeggan_amd.layers import ScaledTanh
+    fx = load_fixture("per_op")
+    x = torch.from_numpy(fx["tanh_c"]).float().to(dev).requires_grad_(True)
+    y = ScaledTanh()(x)
+    assert rel(y, fx["tanh_y"]) < TOL
+    gy = torch.randn(y.shape, device=dev)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    ref = gy.double().cpu() * 0.5 * (1 - torch.tanh(0.5 * torch.from_numpy(fx["tanh_c"])) ** 2)
+    assert rel(gx, ref) < TOL
+
+
+def test_flip_cache_of_a_copied_network(dev):
+    """An input gradient through a deep copy of a layer uses the COPY's current weights: after the copy's
+    weight changes, its flipped view is rebuilt even though the original's caches are up to date."""
+    import copy
+    from eeggan_amd.layers import EqualizedConv1d
+    ops = _ops()
+    torch.manual_seed(3)
+    conv = EqualizedConv1d(8, 12, 3, 1, False, True, "kaiming_normal", 0.2, True, 1, 1).to(dev)
+    x = torch.randn(2, 8, 40, device=dev, requires_grad=True)
+    gy = torch.randn(2, 12, 40, device=dev)
+    torch.autograd.grad(conv(x), x, gy)  # builds the original's view
+    twin = copy.deepcopy(conv)
+    with torch.no_grad():
+        twin.conv.weight.mul_(-2.0)
+    (gx,) = torch.autograd.grad(twin(x), x, gy)
+    ref = F.conv_transpose1d(gy.double().cpu(), twin.conv.weight.detach().double().cpu(), padding=1) * twin.scale
+    assert rel(gx, ref) < TOL
+    (gx0,) = torch.autograd.grad(conv(x), x, gy)  # the original still answers with its own weights
+    ref0 = F.conv_transpose1d(gy.double().cpu(), conv.conv.weight.detach().double().cpu(), padding=1) * conv.scale
+    assert rel(gx0, ref0) < TOL
