@@ -11,6 +11,7 @@ hipGraph and replayed with fresh inputs copied into static buffers.
 from __future__ import annotations
 
 import inspect
+import os
 from typing import Callable, Optional
 
 import torch
@@ -42,6 +43,109 @@ class GraphedCall:
         self.graph.replay()
         # a replay may step an optimizer (weights change with no Python in between) and rewrites the shared
         # flipped-weight views with the weights it started from: eager code that runs next must rebuild them
+        ops.bump_weights_epoch()
+        return self.out
+
+
+class _SplitCriticIteration:
+    """One critic iteration as THREE captured graphs instead of one.
+
+    The critic loss is a sum of a term of the stacked [reals; fakes] pass alone and a term of the
+    interpolates' pass alone (``losses.discriminator_loss(part=...)``), so the two passes -- forward and
+    backward -- never meet before the weight gradients are summed.  Each is a chain of short kernels (5-25 us
+    at 32 samples per GPU) whose launch gaps and partly filled last rounds the other chain can fill:
+
+        graph A (launch stream): stacked pass, its loss term, its backward; weight-gradient slabs only
+        graph B (side stream)  : interpolates' pass, create_graph input gradient, penalty, double backward
+        graph C (launch stream, behind both): slab sums of A and B, loss sum, [bucket pack | Adam + new
+                                 flipped weight views for the next iteration]
+
+    Every graph is a single chain captured on one stream; A and B are replayed on two real streams and
+    ordered by ordinary stream waits.  (One captured graph with two parallel branches was measured first: on
+    ROCm 7.2 its origin-stream branch started before earlier work of the launch stream had finished.)"""
+
+    def __init__(self, trainer, d_loss_fn, sync, bucketed, warmup=3):
+        self.trainer, self.sync, self.bucketed = trainer, sync, bucketed
+        dis, gen, opt = trainer.discriminator, trainer.generator, trainer.optimizer_d
+        self.side = torch.cuda.Stream()  # default priority
+        self.bucket = None
+
+        def chain(part):
+            loss = d_loss_fn(dis, gen, {"x": trainer._real}, {"z": trainer._z}, part=part,
+                             zero_grad=(part == "scores"))
+            with ops.direct_weight_grads(trainer.direct_grads, deferred=True):
+                loss.backward()
+            # gradients that took autograd's own route (the full-length layer's): kept per chain
+            stash = [(p, p.grad) for p in dis.parameters() if p.grad is not None]
+            for p, _ in stash:
+                p.grad = None
+            return loss.detach(), stash
+
+        def close(la, lb, sa, sb):
+            ops.flush_direct_grads()  # slab sums of both chains -> p.grad of the conv weights
+            parts = {}
+            for p, g in sa + sb:
+                parts.setdefault(p, []).append(g)
+            for p, gs in parts.items():
+                p.grad = gs[0] if len(gs) == 1 else gs[0] + gs[1]
+            loss = la + lb
+            if bucketed:
+                self.bucket = sync.pack(dis)
+            else:
+                self._step(opt, dis)
+            return loss
+
+        def whole():
+            la, sa = chain("scores")
+            lb, sb = chain("penalty")
+            return close(la, lb, sa, sb)
+
+        cur = torch.cuda.current_stream()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):
+            for _ in range(warmup):
+                whole()
+                if bucketed:
+                    sync.apply(opt, self.bucket)
+                    ops.refresh_flipped_weights(dis)
+        cur.wait_stream(warm)
+        torch.cuda.synchronize()
+        # the chains read the flipped weight views the closing graph of the previous iteration has built
+        # (the warm-up's last step just did): nothing may rebuild them inside A or B, which run side by side
+        ops.refresh_flipped_weights(dis)
+        torch.cuda.synchronize()
+        try:
+            self.graph_a, self.graph_b, self.graph_c = (torch.cuda.CUDAGraph() for _ in range(3))
+            with torch.cuda.graph(self.graph_a):
+                la, sa = chain("scores")
+            with torch.cuda.graph(self.graph_b):
+                lb, sb = chain("penalty")
+            with torch.cuda.graph(self.graph_c):
+                self.out = close(la, lb, sa, sb)
+        except BaseException:
+            ops.discard_direct_grads()
+            raise
+        self.apply = GraphedCall(lambda: self._step(opt, dis, grads=self.bucket)) if bucketed else None
+
+    def _step(self, opt, dis, grads=None):
+        if grads is not None:
+            self.sync.apply(opt, grads)
+        else:
+            opt.step()
+        ops.refresh_flipped_weights(dis)  # for the next iteration's chains
+
+    def __call__(self):
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.graph_b.replay()
+        self.graph_a.replay()
+        main.wait_stream(self.side)
+        self.graph_c.replay()
+        if self.bucketed:
+            self.sync.reduce(self.bucket)  # the collective runs between two replays, never inside a capture
+            self.apply()
         ops.bump_weights_epoch()
         return self.out
 
@@ -99,6 +203,9 @@ class GraphedTrainer(Trainer):
 
     # generate the fakes of all critic iterations of a step in one generator pass
     batch_fakes = True
+    # run the two independent halves of a critic iteration side by side on two streams (needs batch_fakes and
+    # a critic loss that can be asked for its parts); EEGGAN_SPLIT_CRITIC=0 keeps one graph on one stream
+    split_critic = os.environ.get("EEGGAN_SPLIT_CRITIC", "1") != "0"
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -138,7 +245,7 @@ class GraphedTrainer(Trainer):
 
             self._fakes_call = GraphedCall(all_fakes)
             self._fake = self._fakes_call.out[:z.shape[0]].clone()
-            d_loss_fn = lambda dis, gen, r, zz: self.d_loss(dis, gen, r, zz, fake=self._fake)  # noqa: E731
+            d_loss_fn = lambda dis, gen, r, zz, **kw: self.d_loss(dis, gen, r, zz, fake=self._fake, **kw)  # noqa: E731
 
         def iteration(loss_fn, module, optimizer):
             """(graph of forward + backward [+ bucket pack], bucket, graph of the optimizer step)."""
@@ -160,9 +267,15 @@ class GraphedTrainer(Trainer):
             bucket = box["bucket"]
             return first, bucket, GraphedCall(lambda: sync.apply(optimizer, bucket))
 
-        self._d_parts = iteration(d_loss_fn, self.discriminator, self.optimizer_d)
+        if self.split_critic and self._fake is not None and _accepts(self.d_loss, "part"):
+            self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed)
+        else:
+            self._d_parts = iteration(d_loss_fn, self.discriminator, self.optimizer_d)
         self._g_parts = iteration(self.g_loss, self.generator, self.optimizer_g)
         _restore(snap)
+        # (a split critic iteration reads the views its predecessor's closing graph built: the first one
+        # needs them built here, from the restored weights)
+        ops.refresh_flipped_weights(self.discriminator)
         self._key = key
 
     def _sync_alpha(self):
@@ -176,6 +289,8 @@ class GraphedTrainer(Trainer):
             # (at alpha == 1 the networks take the branch without a blend and never read alpha_dev)
 
     def _replay(self, parts):
+        if callable(parts):
+            return parts()
         first, bucket, second = parts
         loss = first()
         if bucket is not None:
@@ -219,5 +334,6 @@ class GraphedTrainer(Trainer):
             d_loss = self._replay(self._d_parts)
         self._z.copy_(zs[repeats])
         g_loss = self._replay(self._g_parts)
+        self.last_losses = (g_loss, d_loss)  # device scalars of the step's last iterations
         self.iterations += 1
         self.call_plugins("iteration", self.iterations, *(g_loss, d_loss))

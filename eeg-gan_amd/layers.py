@@ -72,7 +72,8 @@ class _DropPool:
         self._chunks.clear()
 
     def take(self, n, base, device):
-        key = (str(device), float(base))
+        # a chunk belongs to the stream that drew it: passes that run side by side on two streams draw their own
+        key = (str(device), float(base), torch.cuda.current_stream().cuda_stream)
         ent = self._chunks.get(key)
         n4 = (n + 3) & ~3
         if ent is None or ent[1] + n4 > ent[0].numel():

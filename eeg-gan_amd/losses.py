@@ -19,7 +19,6 @@ from .utils import cudize
 one = None
 mixing_factors = None
 
-
 def get_mixing_factor(batch_size):
     """A cached [B, 1, 1] buffer refilled with U[0, 1) at every call (reference losses.py:13-18)."""
     global mixing_factors
@@ -34,6 +33,16 @@ def get_one(batch_size):
     if one is None or batch_size != one.size(0):
         one = cudize(torch.ones(batch_size))
     return one
+
+
+zero = None
+
+
+def get_zero(batch_size):
+    global zero
+    if zero is None or batch_size != zero.size(0):
+        zero = cudize(torch.zeros(batch_size))
+    return zero
 
 
 def calc_grad(x_hat, pred_hat):
@@ -77,22 +86,31 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
                        iwass_drift_epsilon: float, grad_lambda: float, iwass_target: float,
                        mixing: Optional[torch.Tensor] = None, stack_real_fake: Optional[bool] = None,
-                       fake: Optional[torch.Tensor] = None):
+                       fake: Optional[torch.Tensor] = None, part: Optional[str] = None,
+                       zero_grad: bool = True):
     """WGAN-GP critic loss.  ``mixing`` optionally supplies the per-sample interpolation factors
     [B, 1, 1] (otherwise drawn like the reference does); used by parity tests.  ``stack_real_fake``:
     evaluate reals and fakes in one stacked critic pass (default: when GDrop noise is drawn on the device).
     ``fake``: fakes generated beforehand from ``z`` with the current generator (a trainer may generate
     the fakes of all critic iterations of a step in one pass: the generator does not change between
-    them, reference trainer.py:83-91); ``gen`` is then not called."""
+    them, reference trainer.py:83-91); ``gen`` is then not called.  ``part`` ('scores' | 'penalty', stacked mode
+    only): return only -mean D(real) + mean D(fake) + drift term, or only the gradient penalty; their sum is
+    the loss.  ``zero_grad=False`` leaves the critic's gradients alone (the second part of a split
+    iteration)."""
     if loss_type != "wgan_gp":
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
         raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
+    if part not in (None, "scores", "penalty"):
+        raise ValueError(f"part={part!r}")
     layers.drop_pool_reset()
-    dis.zero_grad()
+    if zero_grad:
+        dis.zero_grad()
     real_x = real["x"] if isinstance(real, dict) else real
     if stack_real_fake is None:
         stack_real_fake = layers.get_drop_mode() == "device"
+    if part is not None and not stack_real_fake:
+        raise ValueError("part needs the stacked critic pass")
     if stack_real_fake:
         # one critic pass over [reals; fakes]: half the launches, twice the work per launch, and one
         # gradient contribution per weight instead of two.  The reference evaluates the two passes
@@ -106,12 +124,21 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         else:
             fake_x = fake
         n = real_x.size(0)
-        with layers.batch_segments(2):
-            scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+        # The loss is a sum of a term of the stacked pass alone and a term of the interpolates' pass alone
+        # (reference losses.py:94-100 and 106-119), so the two passes and their backward passes are
+        # independent: ``part`` asks for one of them (a graph trainer runs them side by side on two streams).
+        if part in (None, "scores"):
+            with layers.batch_segments(2):
+                scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+            if part == "scores":
+                nothing = get_zero(n).view(n, 1)  # no penalty: lambda = 0 on an all-zero "gradient"
+                return ops.wgan_gp_d_loss_stacked(scores, nothing, iwass_drift_epsilon, 0.0, iwass_target)
         alpha = get_mixing_factor(n) if mixing is None else mixing
         x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
         pred_hat, _, _ = dis(x_hat)
         g = calc_grad(x_hat["x"], pred_hat).view(n, -1)
+        if part == "penalty":
+            return ops.wgan_gp_d_loss(get_zero(n), get_zero(n), g, 0.0, grad_lambda, iwass_target)
         return ops.wgan_gp_d_loss_stacked(scores, g, iwass_drift_epsilon, grad_lambda, iwass_target)
     else:
         d_real, _, _ = dis(real)

@@ -138,6 +138,17 @@ class FlipCache:
         return self.wt
 
 
+def refresh_flipped_weights(module):
+    """Rebuild, on the current stream, every stale flipped view of ``module`` that an input gradient has asked
+    for before (one launch).  For callers that run passes over the module on several streams: the views are
+    shared, so they are rebuilt once, ahead of the passes, on a stream all of them wait for."""
+    for m in module.modules():
+        c = getattr(m, "_flip", None)
+        if isinstance(c, FlipCache) and c.used and c._stale():
+            c.get()
+            return  # one launch rebuilt every stale view of this device
+
+
 def flipped_weights(w, cache=None):
     if cache is not None:
         return cache.get()
@@ -255,7 +266,8 @@ WGRAD_SOLO_UNITS = 16 * 256
 class _DirectGrads:
     def __init__(self):
         self.enabled = False
-        self.stream = None
+        self.deferred = False  # leave the slab sums of the pass to a later flush() (several passes, one sum)
+        self.streams = {}   # stream handle -> torch stream: every stream a slab kernel of this pass ran on
         self.keep = []      # workspaces the pending reductions still read
         self.jobs = []      # (round, job): jobs of one round write distinct buffers
         self.touched = {}   # id(param) -> [param, contributions so far in this backward pass]
@@ -265,6 +277,7 @@ class _DirectGrads:
     def reset(self):
         """Forget everything queued: a backward pass that raised never ran ``finish``."""
         self.touched, self.keep, self.jobs, self.pending, self.queued = {}, [], [], {}, False
+        self.streams = {}
 
     def usable(self, w):
         return self.enabled and not torch.is_grad_enabled() and w.is_leaf and w.requires_grad and w.is_cuda
@@ -304,14 +317,16 @@ class _DirectGrads:
         job = _WgradJob(x.data_ptr(), gy.data_ptr(), _p(mask_y), _p(mask_drop), ws.data_ptr(), nbytes, B, Cin, Cout,
                         T, K, int(bias is not None), float(in_scale), float(slope))
         # the tensors stay referenced until the group is submitted: nothing may recycle their memory
-        # (jobs that run the same kernel variant share a launch, so they are queued per variant)
-        variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0)
+        # (jobs that run the same kernel variant ON THE SAME STREAM share a launch: backward nodes run on the
+        # stream of their forward pass, and two critic passes may run side by side on two streams)
+        stream = torch.cuda.current_stream()
+        self.streams[stream.cuda_stream] = stream
+        variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0, stream.cuda_stream)
         units = ((Cout + 63) // 64) * ((Cin + 63) // 64) * ((B * ((T + 31) // 32) + 1) // 2)
         if units >= WGRAD_SOLO_UNITS:
-            variant = (variant, len(self.jobs))  # a queue of its own, submitted right away
+            variant = variant + (len(self.jobs),)  # a queue of its own, submitted right away
         queue = self.pending.setdefault(variant, [])
         queue.append((job, (x, gy, mask_y, mask_drop, ws), (w, bias)))
-        self.stream = _stream()
         if not self.queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self.queued = True
@@ -331,7 +346,7 @@ class _DirectGrads:
         n = len(pending)
         table = (_WgradJob * n)(*[p[0] for p in pending])
         jw, jb = (_ReduceJob * n)(), (_ReduceJob * n)()
-        call("eeggan_conv1d_wgrad_partial_multi", table, n, jw, jb, self.stream)
+        call("eeggan_conv1d_wgrad_partial_multi", table, n, jw, jb, variant[2])
         for i, (_, tensors, (w, bias)) in enumerate(pending):
             for p, src in ((w, jw[i]), (bias, jb[i])):
                 if p is not None:
@@ -342,12 +357,35 @@ class _DirectGrads:
             self.keep.append(tensors[4])
 
     def finish(self):
+        if self.deferred:
+            # only the slab kernels of this pass; their sums wait for flush() (which the caller orders behind
+            # the streams of all the passes it collects)
+            try:
+                self.submit()
+            except BaseException:
+                self.reset()
+                raise
+            self.queued = False
+            return
+        self.flush(sync_streams=True)
+
+    def flush(self, sync_streams=False):
+        """Sum the slabs of everything collected since the last flush into the parameters' gradient buffers
+        and make those ``p.grad``.  ``sync_streams``: first make the current stream wait for the streams the
+        slab kernels ran on (otherwise the caller has ordered the current stream behind them)."""
         try:
             self.submit()
+            # the slab sums run on the current stream, behind the slab kernels of every stream of this pass
+            here = torch.cuda.current_stream()
+            for handle, stream in (self.streams.items() if sync_streams else ()):
+                if handle != here.cuda_stream:
+                    event = torch.cuda.Event()
+                    event.record(stream)
+                    here.wait_event(event)
             for rnd in sorted({r for r, _ in self.jobs}):
                 jobs = [j for r, j in self.jobs if r == rnd]
                 table = (_ReduceJob * len(jobs))(*jobs)
-                call("eeggan_wgrad_reduce_multi", table, len(jobs), self.stream)
+                call("eeggan_wgrad_reduce_multi", table, len(jobs), here.cuda_stream)
             for p, _ in self.touched.values():
                 p.grad = p._eeggan_grad
         finally:
@@ -395,20 +433,32 @@ def conv1d_wgrad_group_raw(jobs):
     return outs
 
 
+def flush_direct_grads():
+    """Close a series of backward passes run under ``direct_weight_grads(deferred=True)``: one set of slab
+    sums for all of them, on the current stream, which the caller has ordered behind those passes."""
+    _direct.flush(sync_streams=False)
+
+
+def discard_direct_grads():
+    """Forget what deferred passes have collected (their slabs are never summed)."""
+    _direct.reset()
+
+
 @contextlib.contextmanager
-def direct_weight_grads(enabled=True):
+def direct_weight_grads(enabled=True, deferred=False):
     if _direct.queued:
         # left over from a backward pass that raised after queueing work (the engine then never ran the
         # end-of-backward callback): without this every later pass would skip registering it
         _direct.reset()
-    prev, _direct.enabled = _direct.enabled, bool(enabled)
+    prev, _direct.enabled = (_direct.enabled, _direct.deferred), bool(enabled)
+    _direct.deferred = bool(deferred)
     try:
         yield
     except BaseException:
         _direct.reset()
         raise
     finally:
-        _direct.enabled = prev
+        _direct.enabled, _direct.deferred = prev
 
 
 def lrelu_drop_bwd_raw(g, y, drop, slope):

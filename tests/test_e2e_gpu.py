@@ -371,9 +371,10 @@ def test_headline_configuration_against_oracle(dev):
 def test_benchmarked_launch_path_against_oracle(dev, alpha):
     """The launch path ``bench.py`` times, at the configuration it times (final stage, T = 1920, 32 samples;
     alpha 1 and mid-transition): ``GraphedTrainer`` with device-side noise handling, i.e. ONE stacked critic
-    pass over [reals; fakes] (64 samples), ONE generator pass over the latents of all five critic iterations
-    (160 samples), weight gradients deposited directly in groups, Adam inside the graphs, every iteration a
-    graph replay -- against the fp64 oracle's five critic iterations and generator iteration
+    pass over [reals; fakes] (64 samples) and the interpolates' pass as two chains on two streams (three
+    graphs per critic iteration), ONE generator pass over the latents of all five critic iterations
+    (160 samples), weight gradients deposited directly in groups, Adam inside the graphs, every iteration
+    graph replays -- against the fp64 oracle's five critic iterations and generator iteration
     (reference losses.py:73-120, 40-48; trainer.py:79-96).  GDrop strength is 0 so that both sides see the
     same multipliers, the mixing factors are fixed, and lr = 0 keeps the weights in place, so with beta1 = 0
     Adam's first moment IS the last iteration's gradient and its second moment the decayed sum of squares of
@@ -417,7 +418,8 @@ def test_benchmarked_launch_path_against_oracle(dev, alpha):
         tr.train()
         torch.cuda.synchronize()
         assert tr._fakes_call is not None and tr._zall.shape[0] == repeats * B, "one generator pass per step"
-        d_loss, g_loss = float(tr._d_parts[0].out), float(tr._g_parts[0].out)
+        g_loss, d_loss = (float(v) for v in tr.last_losses)
+        assert type(tr._d_parts).__name__ == "_SplitCriticIteration", "the critic iteration runs as two chains"
         moments = lambda net, opt: [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
                                     if p in opt.state else None for p in net.parameters()]
         d_mom, g_mom = moments(d, opt_d), moments(g, opt_g)
