@@ -29,6 +29,9 @@ if ROOT not in sys.path:
 DEPTH, ALPHA, BATCH = 7, 1.0, 32
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # 256 CUs x 4 SIMDs x 32*32*16*2 flop / 32 cycles x 2.4 GHz
+# algorithmic conv flops of one step per sample, 8 F_G + 62 F_D (5 critic + 1 generator iteration; the
+# critic's weight gradients the reference computes and never uses are not counted)
+STEP_GFLOP_PER_SAMPLE = {7: 33.41, 0: 1.183}
 
 
 def parse():
@@ -94,51 +97,135 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_
     return tr
 
 
+HBM_PEAK_GBS = 8000.0
+
+
 def conv_roofline(dev, batch, T):
     """Dominant kernel: the 64->64, k=3 same-padded conv at T=1920 (54 % of the step's FLOPs are
-    64-channel k=3 convs).  Average launch duration measured with HIP events on the launch stream."""
+    64-channel k=3 convs).  ``avg_launch_us`` brackets EVERY launch with its own pair of HIP events on the
+    launch stream (the figure a rocprofv3 kernel trace of this command reports per dispatch);
+    ``back_to_back_us`` is one pair of events around the whole run of launches (successive launches then
+    overlap their ramp-up and drain)."""
     from eeggan_amd import ops
     C, K = 64, 3
     x = torch.randn(batch, C, T, device=dev)
     w = torch.randn(C, C, K, device=dev)
     b = torch.randn(C, device=dev)
     r = torch.rand(batch, C, device=dev) + 0.5
+    launch = lambda: ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2)
     for _ in range(5):
-        ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2)
+        launch()
     n = 50
     st = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n)]
+    for i in range(n):
+        ev[2 * i].record(st)
+        launch()
+        ev[2 * i + 1].record(st)
+    ev[-1].synchronize()
+    per_launch = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(n)) * 1e-3 / n
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(n):
-        ops.conv1d_raw(x, w, b, r, in_scale=0.1, act=1, act_param=0.2)
+        launch()
     e1.record(st)
     e1.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / n
+    back_to_back = e0.elapsed_time(e1) * 1e-3 / n
     flops = 2.0 * batch * C * C * K * T
-    achieved = flops / sec / 1e12
-    # HBM bytes per launch from the PMC passes kept in profiles/*pmc_conv_ws_64x64_T1920_B32.csv
-    # (2 x FETCH_SIZE + WRITE_SIZE = 2 x 11588.4 KiB + 15360 KiB; the algorithmic figure is 31.5 MB:
-    # input + output once, weights, multipliers).  Only valid for the profiled shape.
+    achieved = flops / per_launch / 1e12
+    # HBM bytes per launch from the PMC passes kept in profiles/*pmc_conv_ws_64x64_T1920_B32.csv:
+    # 2 x FETCH_SIZE + WRITE_SIZE = 2 x 9822.6 KiB + 15360 KiB (gfx950 tallies 128-byte read requests at
+    # 64 bytes); the algorithmic figure is 31.5 MB: input + output once, weights, multipliers.  Only valid
+    # for the profiled shape.
     traffic = (2 * 9822.5625 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
+    algorithmic_bytes = 4.0 * (2 * batch * C * T + C * C * K + C + batch * C)
     # The kernel forms every fp32 product from three bf16 pieces per operand (six bf16 MFMAs per 16
-    # reduction indices, fp32-exact to 2^-24): `achieved`/`frac` price the ALGORITHMIC fp32 flops against
+    # reduction indices, fp32-exact to 2^-24).  `achieved`/`frac` price the ALGORITHMIC fp32 flops against
     # the fp32 matrix peak (the arithmetic type of the path); `pipe_frac` prices the six-fold executed
-    # work against the bf16 pipe it runs on.  EEGGAN_FP32_MFMA=1 selects the fp32 instructions instead.
+    # work against the bf16 pipe it runs on; `bound_frac` prices the algorithmic flops against the tighter
+    # of the two ceilings this formulation has: a sixth of the bf16 pipe, and HBM bandwidth x the layer's
+    # arithmetic intensity.  EEGGAN_FP32_MFMA=1 selects the fp32 instructions instead.
     fp32_mfma = os.environ.get("EEGGAN_FP32_MFMA") is not None
     out = {"bound": "mfma", "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop)" % batch,
            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-           "avg_launch_us": round(sec * 1e6, 2), "flop_per_launch": flops,
+           "avg_launch_us": round(per_launch * 1e6, 2), "back_to_back_us": round(back_to_back * 1e6, 2),
+           "flop_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes,
            "matrix_instruction": "v_mfma_f32_32x32x2_f32" if fp32_mfma else
            "6 x v_mfma_f32_32x32x16_bf16 per 16 reduction indices (three bf16 pieces per fp32 operand)"}
     if not fp32_mfma:
         out["pipe_frac"] = round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)
+        ceiling = min(BF16_MFMA_PEAK_TFLOPS / 6.0, HBM_PEAK_GBS * (flops / algorithmic_bytes) / 1e3)
+        out["bound_tflops"] = round(ceiling, 1)
+        out["bound_frac"] = round(achieved / ceiling, 4)
     return out
 
 
-def cpu_baseline(depth, alpha, batch, seed):
-    """The CPU restatement (oracle, kind 'port') timed on the host cores: whole steps for about ten
-    seconds after one warm-up discriminator iteration."""
+def conv_ws_family_flops(trainer_factory):
+    """Algorithmic flops per training step of all launches that take the weight-stationary kernel (k = 3, at
+    most 64 channels on both sides, >= 256 subtiles: the library's own dispatch rule), counted over one eager
+    step with the same models; with the family's kernel time from a rocprofv3 trace this gives the in-step
+    figure next to the stand-alone one."""
+    from eeggan_amd import ops
+    total = [0.0, 0]
+    raw = ops.conv1d_raw
+
+    def counted(x, w, *a, **k):
+        B, Cin, T = x.shape
+        K = w.shape[2]
+        Cout = w.shape[1] if k.get("transposed") else w.shape[0]
+        if K == 3 and Cin <= 64 and 32 < Cout <= 64 and T % 4 == 0 and B * ((T + 31) // 32) >= 256:
+            total[0] += 2.0 * B * Cin * Cout * K * T
+            total[1] += 1
+        return raw(x, w, *a, **k)
+
+    fused = ops.conv1d_pixelnorm_raw
+
+    def counted_fused(x, w, *a, **k):  # the generator's conv + norm layers take the same kernel when covered
+        out = fused(x, w, *a, **k)
+        if out is not None:
+            total[0] += 2.0 * x.shape[0] * x.shape[1] * w.shape[0] * w.shape[2] * x.shape[2]
+            total[1] += 1
+        return out
+
+    ops.conv1d_raw, ops.conv1d_pixelnorm_raw = counted, counted_fused
+    try:
+        tr = trainer_factory()
+        tr.train()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv1d_raw, ops.conv1d_pixelnorm_raw = raw, fused
+    return total
+
+
+def in_step_figures(flops, launches):
+    """The weight-stationary family inside the training step: flops counted live, kernel time per step from
+    the committed rocprofv3 summary of this command (profiles/r02_bench_per_kernel.txt), if it is there."""
+    out = {"family": "conv_ws_kernel<*>", "flop_per_step": flops, "launches_per_step": launches}
+    path = os.path.join(ROOT, "profiles", "r02_bench_per_kernel.txt")
+    if os.path.exists(path):
+        ms = 0.0
+        for line in open(path):
+            if "conv_ws_kernel" in line and "ms/step=" in line:
+                ms += float(line.split("ms/step=")[1].split()[0])
+        if ms > 0:
+            out.update(kernel_ms_per_step=round(ms, 3), source="profiles/r02_bench_per_kernel.txt",
+                       achieved=round(flops / (ms * 1e-3) / 1e12, 2),
+                       frac=round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_steps(depth, alpha, batch, seed, budget_s, max_steps):
     from eeggan_amd import config
     from oracle import ref_cpu as O
     g, d = config.build_models(config.RANDOM_SEED)
@@ -154,15 +241,28 @@ def cpu_baseline(depth, alpha, batch, seed):
     src = O.DropSource("numpy")
     tr.d_iter(reals[0], zs[0], mixes[0], src, src)  # warm-up
     steps, t0 = 0, time.perf_counter()
-    while True:  # whole steps until ~10 s of CPU work are on the clock (at most 8 steps)
+    while True:  # whole steps until the budget of CPU work is on the clock
         tr.step(reals, zs, mixes, src, src)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt >= 10.0 or steps >= 8:
+        if dt >= budget_s or steps >= max_steps:
             break
-    return {"value": round(steps / dt, 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full steps (5 D + 1 G iterations with Adam each) after 1 warm-up D iteration, "
-                      f"depth {depth}, B={batch}, fp32, torch CPU ops ({dt:.2f} s)"}
+    return steps, dt
+
+
+def cpu_baseline(depth, alpha, batch, seed):
+    """The CPU restatement (oracle, kind 'port') timed on the host cores: whole steps for about ten
+    seconds after one warm-up discriminator iteration at the benchmarked configuration, and a few seconds
+    at the first progression stage (depth 0, the reference's own CPU-runnable case)."""
+    steps, dt = _cpu_steps(depth, alpha, batch, seed, 10.0, 8)
+    out = {"value": round(steps / dt, 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": cpu_model(), "host_cpus_visible": len(os.sched_getaffinity(0)),
+           "sample": f"{steps} full steps (5 D + 1 G iterations with Adam each) after 1 warm-up D iteration, "
+                     f"depth {depth}, B={batch}, fp32, torch CPU ops on {torch.get_num_threads()} threads ({dt:.2f} s)"}
+    steps0, dt0 = _cpu_steps(0, 1.0, 32, seed, 4.0, 12)
+    out["first_stage"] = {"value": round(steps0 / dt0, 5), "unit": "steps/s",
+                          "sample": f"{steps0} full steps at depth 0 (T=32), B=32, alpha=1, fp32 ({dt0:.2f} s)"}
+    return out
 
 
 def main():
@@ -235,6 +335,13 @@ def main():
                        "launch": type(tr).__name__},
         }
         out["roofline"] = conv_roofline(dev, args.batch, T)
+        fam = conv_ws_family_flops(lambda: make_trainer(dev, args.depth, args.alpha, args.batch, 1373, 1, 0, eager=True))
+        out["roofline"]["in_step"] = in_step_figures(*fam)
+        out["roofline"]["whole_step"] = {
+            "flop_per_step": STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * 1e9 * args.batch,
+            "achieved": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3, 2),
+            "frac": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3
+                          / FP32_MFMA_PEAK_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.depth, args.alpha, args.batch, 1373)
         print(json.dumps(out), flush=True)

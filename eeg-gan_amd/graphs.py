@@ -60,19 +60,21 @@ class _SplitCriticIteration:
         graph C (launch stream, behind both): slab sums of A and B, loss sum, [bucket pack | Adam + new
                                  flipped weight views for the next iteration]
 
-    Every graph is a single chain captured on one stream; A and B are replayed on two real streams and
-    ordered by ordinary stream waits.  (One captured graph with two parallel branches was measured first: on
+    (``parts`` names the chains; the score term can be split once more into a reals' and a fakes' chain.)
+    Every graph is a single chain captured on one stream; the chains are replayed on real streams of their
+    own and ordered by ordinary stream waits.  (One captured graph with two parallel branches was measured first: on
     ROCm 7.2 its origin-stream branch started before earlier work of the launch stream had finished.)"""
 
-    def __init__(self, trainer, d_loss_fn, sync, bucketed, warmup=3):
+    def __init__(self, trainer, d_loss_fn, sync, bucketed, warmup=3, parts=("scores", "penalty")):
         self.trainer, self.sync, self.bucketed = trainer, sync, bucketed
         dis, gen, opt = trainer.discriminator, trainer.generator, trainer.optimizer_d
-        self.side = torch.cuda.Stream()  # default priority
+        self.parts = tuple(parts)
+        self.sides = [torch.cuda.Stream() for _ in self.parts[1:]]  # default priority
         self.bucket = None
 
         def chain(part):
             loss = d_loss_fn(dis, gen, {"x": trainer._real}, {"z": trainer._z}, part=part,
-                             zero_grad=(part == "scores"))
+                             zero_grad=(part == self.parts[0]))
             with ops.direct_weight_grads(trainer.direct_grads, deferred=True):
                 loss.backward()
             # gradients that took autograd's own route (the full-length layer's): kept per chain
@@ -81,48 +83,46 @@ class _SplitCriticIteration:
                 p.grad = None
             return loss.detach(), stash
 
-        def close(la, lb, sa, sb):
-            ops.flush_direct_grads()  # slab sums of both chains -> p.grad of the conv weights
-            parts = {}
-            for p, g in sa + sb:
-                parts.setdefault(p, []).append(g)
-            for p, gs in parts.items():
-                p.grad = gs[0] if len(gs) == 1 else gs[0] + gs[1]
-            loss = la + lb
+        def close(results):
+            ops.flush_direct_grads()  # slab sums of all chains -> p.grad of the conv weights
+            grads = {}
+            for _, stash in results:
+                for p, g in stash:
+                    grads[p] = g if p not in grads else grads[p] + g
+            for p, g in grads.items():
+                p.grad = g
+            loss = results[0][0]
+            for other, _ in results[1:]:
+                loss = loss + other
             if bucketed:
                 self.bucket = sync.pack(dis)
             else:
                 self._step(opt, dis)
             return loss
 
-        def whole():
-            la, sa = chain("scores")
-            lb, sb = chain("penalty")
-            return close(la, lb, sa, sb)
-
         cur = torch.cuda.current_stream()
         warm = torch.cuda.Stream()
         warm.wait_stream(cur)
         with torch.cuda.stream(warm):
             for _ in range(warmup):
-                whole()
+                close([chain(part) for part in self.parts])
                 if bucketed:
-                    sync.apply(opt, self.bucket)
-                    ops.refresh_flipped_weights(dis)
+                    self._step(opt, dis, grads=self.bucket)
         cur.wait_stream(warm)
         torch.cuda.synchronize()
         # the chains read the flipped weight views the closing graph of the previous iteration has built
-        # (the warm-up's last step just did): nothing may rebuild them inside A or B, which run side by side
+        # (the warm-up's last step just did): nothing may rebuild them inside a chain, they run side by side
         ops.refresh_flipped_weights(dis)
         torch.cuda.synchronize()
         try:
-            self.graph_a, self.graph_b, self.graph_c = (torch.cuda.CUDAGraph() for _ in range(3))
-            with torch.cuda.graph(self.graph_a):
-                la, sa = chain("scores")
-            with torch.cuda.graph(self.graph_b):
-                lb, sb = chain("penalty")
+            self.graphs = [torch.cuda.CUDAGraph() for _ in self.parts]
+            results = []
+            for graph, part in zip(self.graphs, self.parts):
+                with torch.cuda.graph(graph):
+                    results.append(chain(part))
+            self.graph_c = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_c):
-                self.out = close(la, lb, sa, sb)
+                self.out = close(results)
         except BaseException:
             ops.discard_direct_grads()
             raise
@@ -137,11 +137,13 @@ class _SplitCriticIteration:
 
     def __call__(self):
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self.graph_b.replay()
-        self.graph_a.replay()
-        main.wait_stream(self.side)
+        for side, graph in zip(self.sides, self.graphs[1:]):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                graph.replay()
+        self.graphs[0].replay()
+        for side in self.sides:
+            main.wait_stream(side)
         self.graph_c.replay()
         if self.bucketed:
             self.sync.reduce(self.bucket)  # the collective runs between two replays, never inside a capture
@@ -206,6 +208,7 @@ class GraphedTrainer(Trainer):
     # run the two independent halves of a critic iteration side by side on two streams (needs batch_fakes and
     # a critic loss that can be asked for its parts); EEGGAN_SPLIT_CRITIC=0 keeps one graph on one stream
     split_critic = os.environ.get("EEGGAN_SPLIT_CRITIC", "1") != "0"
+    critic_chains = tuple(os.environ.get("EEGGAN_CRITIC_CHAINS", "scores,penalty").split(","))
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -268,7 +271,7 @@ class GraphedTrainer(Trainer):
             return first, bucket, GraphedCall(lambda: sync.apply(optimizer, bucket))
 
         if self.split_critic and self._fake is not None and _accepts(self.d_loss, "part"):
-            self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed)
+            self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed, parts=self.critic_chains)
         else:
             self._d_parts = iteration(d_loss_fn, self.discriminator, self.optimizer_d)
         self._g_parts = iteration(self.g_loss, self.generator, self.optimizer_g)

@@ -95,13 +95,13 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
     the fakes of all critic iterations of a step in one pass: the generator does not change between
     them, reference trainer.py:83-91); ``gen`` is then not called.  ``part`` ('scores' | 'penalty', stacked mode
     only): return only -mean D(real) + mean D(fake) + drift term, or only the gradient penalty; their sum is
-    the loss.  ``zero_grad=False`` leaves the critic's gradients alone (the second part of a split
+    the loss ('real' and 'fake' split the score term once more, into a critic pass each).  ``zero_grad=False`` leaves the critic's gradients alone (the second part of a split
     iteration)."""
     if loss_type != "wgan_gp":
         raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
     if grad_lambda == 0:
         raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
-    if part not in (None, "scores", "penalty"):
+    if part not in (None, "scores", "penalty", "real", "fake"):
         raise ValueError(f"part={part!r}")
     layers.drop_pool_reset()
     if zero_grad:
@@ -127,6 +127,12 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         # The loss is a sum of a term of the stacked pass alone and a term of the interpolates' pass alone
         # (reference losses.py:94-100 and 106-119), so the two passes and their backward passes are
         # independent: ``part`` asks for one of them (a graph trainer runs them side by side on two streams).
+        if part in ("real", "fake"):  # the two halves of the score term, one critic pass each
+            score, _, _ = dis({"x": real_x if part == "real" else fake_x})
+            nothing, zeros = get_zero(n).view(n, 1), get_zero(n)
+            if part == "real":
+                return ops.wgan_gp_d_loss(score, zeros, nothing, iwass_drift_epsilon, 0.0, iwass_target)
+            return ops.wgan_gp_d_loss(zeros, score, nothing, 0.0, 0.0, iwass_target)
         if part in (None, "scores"):
             with layers.batch_segments(2):
                 scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
