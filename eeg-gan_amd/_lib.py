@@ -65,6 +65,14 @@ SIGNATURES = {
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_mean_scale_bwd": (_i, [_f, _f, _i, _fl, _st]),
+    "eeggan_swd_patches": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
+    "eeggan_swd_normalize_workspace": (_sz, []),
+    "eeggan_swd_normalize": (_i, [_f, _sz, _i, _fl, C.c_void_p, _sz, _st]),
+    "eeggan_swd_project_keys": (_i, [_f, _f, C.c_void_p, _sz, _i, _i, _st]),
+    "eeggan_swd_sort_workspace": (_sz, [_sz, _i]),
+    "eeggan_swd_sort": (_i, [C.c_void_p, C.c_void_p, _sz, _i, C.c_void_p, _sz, _st]),
+    "eeggan_swd_distance_workspace": (_sz, []),
+    "eeggan_swd_distance": (_i, [C.c_void_p, C.c_void_p, _sz, _f, C.c_void_p, _sz, _st]),
     "eeggan_adam_step": (_i, [C.c_void_p, _i, _fl, _fl, _fl, _fl, _fl, _st]),
     "eeggan_multi_copy": (_i, [C.c_void_p, _i, _st]),
 }

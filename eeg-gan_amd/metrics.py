@@ -1,0 +1,154 @@
+"""Evaluation metrics of the reference's plugins on the device (reference plugins.py:361-451: the 1-D sliced
+Wasserstein distance).  Same class name, constructor and methods as the reference's plugin; the patches,
+their normalisation, the projections, the sort and the distance run as HIP kernels, and the generated and
+real batches never leave the GPU (the reference moves them to the host, plugins.py:408).
+
+Random draws follow the reference exactly: patch positions come one by one from numpy's global generator
+(plugins.py:442) and the directions from torch's CPU generator (plugins.py:386), in the reference's order, so
+equal seeds give equal draws."""
+from __future__ import annotations
+
+import gc
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .plugins import Plugin
+from .utils import cudize
+
+EPSILON = 1e-8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a HIP device tensor, got {t.device}; this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class SlicedWDistance(Plugin):
+    def __init__(self, progression_scale: int, output_snapshot_ticks: int, patches_per_item: int = 16,
+                 patch_size: int = 49, max_items: int = 1024, number_of_projections: int = 512,
+                 dir_repeats: int = 4, dirs_per_repeat: int = 128):
+        super().__init__([(1, "epoch")])
+        self.output_snapshot_ticks = output_snapshot_ticks
+        self.progression_scale = progression_scale
+        self.patches_per_item = patches_per_item
+        self.patch_size = patch_size
+        self.max_items = max_items
+        self.number_of_projections = number_of_projections
+        self.dir_repeats = dir_repeats
+        self.dirs_per_repeat = dirs_per_repeat
+
+    def register(self, trainer):
+        self.trainer = trainer
+        self.trainer.stats["swd"] = {"log_name": "swd", "log_epoch_fields": ["{val:.2f}", "{epoch:.2f}"],
+                                     "val": float("nan"), "epoch": 0}
+
+    # ---- device pieces ---------------------------------------------------------------------------------
+    def _sorted_projections(self, desc: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+        """64-bit keys (direction << 32 | ordered float), every direction's projections sorted and contiguous."""
+        rows, c = desc.shape
+        D = dirs.shape[1]
+        n = rows * D
+        keys = torch.empty(n, device=desc.device, dtype=torch.int64)
+        out = torch.empty_like(keys)
+        call("eeggan_swd_project_keys", desc.data_ptr(), dirs.data_ptr(), keys.data_ptr(), rows, c, D, _stream())
+        nbytes = _lib.load().eeggan_swd_sort_workspace(n, D)
+        ws = torch.empty(nbytes, device=desc.device, dtype=torch.uint8)
+        call("eeggan_swd_sort", keys.data_ptr(), out.data_ptr(), n, D, ws.data_ptr(), nbytes, _stream())
+        return out
+
+    def sliced_wasserstein(self, A, B):
+        """Mean over ``dir_repeats`` sets of ``dirs_per_repeat`` random unit directions of the mean absolute
+        difference between the sorted projections of A and B ([rows, components], equal shapes)."""
+        A, B = _dev_f32(A, "sliced_wasserstein A"), _dev_f32(B, "sliced_wasserstein B")
+        if A.shape != B.shape or A.dim() != 2:
+            raise RuntimeError(f"sliced_wasserstein: shapes {tuple(A.shape)} and {tuple(B.shape)} must agree")
+        lib = _lib.load()
+        nbytes = lib.eeggan_swd_distance_workspace()
+        ws = torch.empty(nbytes, device=A.device, dtype=torch.uint8)
+        results = torch.empty(self.dir_repeats, device=A.device, dtype=torch.float32)
+        for repeat in range(self.dir_repeats):
+            dirs = torch.randn(A.shape[1], self.dirs_per_repeat)  # host generator, like the reference
+            dirs /= torch.sqrt((dirs * dirs).sum(dim=0, keepdim=True) + EPSILON)
+            dirs = dirs.contiguous().to(A.device)
+            ka, kb = self._sorted_projections(A, dirs), self._sorted_projections(B, dirs)
+            call("eeggan_swd_distance", ka.data_ptr(), kb.data_ptr(), ka.numel(), results[repeat:].data_ptr(),
+                 ws.data_ptr(), nbytes, _stream())
+        return float(results.double().mean().item())
+
+    def _descriptors(self, batch: torch.Tensor, items: int, step: int = 1) -> torch.Tensor:
+        """Normalised patch descriptors of ``batch[:, :, ::step]``: [items * patches_per_item * patch_size, c]."""
+        _, c, t_full = batch.shape
+        t_level = -(-t_full // step)  # length of batch[:, :, ::step]
+        max_index = t_level - self.patch_size
+        n = items * self.patches_per_item
+        starts = np.empty(n, dtype=np.int32)
+        for i in range(n):  # one draw per patch, in the reference's order (plugins.py:440-442)
+            starts[i] = np.random.randint(0, max_index)
+        starts_d = torch.from_numpy(starts).to(batch.device)
+        desc = torch.empty((n * self.patch_size, c), device=batch.device, dtype=torch.float32)
+        call("eeggan_swd_patches", batch.data_ptr(), starts_d.data_ptr(), desc.data_ptr(), items, c, t_full, step,
+             self.patches_per_item, self.patch_size, _stream())
+        nbytes = _lib.load().eeggan_swd_normalize_workspace()
+        ws = torch.empty(nbytes, device=batch.device, dtype=torch.uint8)
+        call("eeggan_swd_normalize", desc.data_ptr(), desc.shape[0], c, EPSILON, ws.data_ptr(), nbytes, _stream())
+        return desc
+
+    def get_descriptors(self, batch1, batch2):
+        """One distance per "pyramid level" (as many levels as the signal can be divided by
+        ``progression_scale`` while staying at least a patch long).  Like the reference as written, every level
+        takes fresh random patches from the FULL-RATE batches: it rebuilds its batch list from the originals at
+        the top of each level (plugins.py:436) and decimates only after the patches are taken (plugins.py:449),
+        so the decimated signals are never read."""
+        batch1, batch2 = _dev_f32(batch1, "get_descriptors batch1"), _dev_f32(batch2, "get_descriptors batch2")
+        b, c, t_max = batch1.shape
+        if batch2.shape[0] < b or batch2.shape[1] != c:
+            raise RuntimeError("get_descriptors: the second batch needs at least as many items and equal channels")
+        if self.progression_scale < 2:
+            raise ValueError("progression_scale must be at least 2")
+        num_levels, t = 0, t_max
+        while t >= self.patch_size:
+            num_levels += 1
+            t //= self.progression_scale
+        swd = []
+        for _ in range(num_levels):
+            d1 = self._descriptors(batch1, b)
+            d2 = self._descriptors(batch2, b)
+            swd.append(self.sliced_wasserstein(d1, d2))
+        return swd
+
+    def epoch(self, epoch_index):
+        if epoch_index % self.output_snapshot_ticks != 0:
+            return
+        gc.collect()
+        all_fakes, all_reals = [], []
+        with torch.no_grad():
+            remaining = self.max_items
+            while remaining > 0:
+                z = cudize(next(self.trainer.random_latents_generator))
+                all_fakes.append(self.trainer.generator(z)[0]["x"].detach())
+                if all_fakes[-1].size(2) < self.patch_size:
+                    break
+                remaining -= all_fakes[-1].size(0)
+            all_fakes = torch.cat(all_fakes, dim=0)
+            remaining = self.max_items
+            while remaining > 0:
+                all_reals.append(cudize(next(self.trainer.dataiter))["x"])
+                if all_reals[-1].size(2) < self.patch_size:
+                    break
+                remaining -= all_reals[-1].size(0)
+            all_reals = torch.cat(all_reals, dim=0)
+        swd = self.get_descriptors(all_fakes, all_reals)
+        if len(swd) > 0:
+            swd.append(np.array(swd).mean())
+        self.trainer.stats["swd"]["val"] = swd
+        self.trainer.stats["swd"]["epoch"] = epoch_index

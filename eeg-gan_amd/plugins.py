@@ -106,3 +106,12 @@ class DepthManager(Plugin):
             self.alpha = alpha
         tr.stats["depth"] = depth
         tr.stats["alpha"]["val"] = alpha
+
+
+def __getattr__(name):
+    # the metric plugins keep the reference's import path (plugins.SlicedWDistance, plugins.FidCalculator) but
+    # live in metrics.py, which imports this module for the Plugin base class
+    if name in ("SlicedWDistance", "FidCalculator"):
+        from . import metrics
+        return getattr(metrics, name)
+    raise AttributeError(name)

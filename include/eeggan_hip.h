@@ -248,6 +248,34 @@ int eeggan_adam_step(const eeggan_adam_tensor* table, int ntensors,
  * of one flat bucket for a single all-reduce. */
 int eeggan_multi_copy(const eeggan_adam_tensor* table, int ntensors, void* stream);
 
+/* ---- 1-D sliced Wasserstein distance (SlicedWDistance, plugins.py:383-395, 426-451) -----------------
+ * The metric of the reference's evaluation plugin, on the device.  Per pyramid level:
+ *   eeggan_swd_patches: out[(j*ppi + k), ch, p] = batch[j, ch, (starts[j*ppi + k] + p) * step]
+ *       (plugins.py:439-444; `step` is the decimation of the level, batchs[i][:, :, ::scale] applied
+ *       `level` times, plugins.py:449, without materialising the decimated batch; T = full length);
+ *   eeggan_swd_normalize: the patches read as rows of c numbers, desc[rows, c] (the reference's
+ *       reshape((-1, c)), plugins.py:445):  desc = (desc - mean_col) / (std_col + eps), std unbiased
+ *       (plugins.py:446-447); sums in double precision, fixed order;
+ *   eeggan_swd_project_keys: keys[d*rows + m] = d << 32 | ord(sum_k desc[m,k] * dirs[k,d]) for the D unit
+ *       directions dirs[c, D] (plugins.py:386-390); ord() maps a float to an unsigned integer of the same order;
+ *   eeggan_swd_sort: one device-wide radix sort of the keys over 32 + ceil(log2 D) bits = every direction's
+ *       projections sorted and contiguous (torch.sort(dim=0), plugins.py:391-392);
+ *   eeggan_swd_distance: out[0] = mean |a - b| over the two sorted key arrays (plugins.py:393-394).
+ * Workspaces are caller-allocated device memory of the sizes the _workspace functions return. */
+int eeggan_swd_patches(const float* batch, const int32_t* starts, float* out, int items, int c, int T,
+                       int step, int patches_per_item, int patch_size, void* stream);
+size_t eeggan_swd_normalize_workspace(void);
+int eeggan_swd_normalize(float* desc, size_t rows, int c, float eps, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int eeggan_swd_project_keys(const float* desc, const float* dirs, uint64_t* keys, size_t rows, int c, int D,
+                            void* stream);
+size_t eeggan_swd_sort_workspace(size_t nkeys, int D);
+int eeggan_swd_sort(const uint64_t* keys_in, uint64_t* keys_out, size_t nkeys, int D, void* workspace,
+                    size_t workspace_bytes, void* stream);
+size_t eeggan_swd_distance_workspace(void);
+int eeggan_swd_distance(const uint64_t* a, const uint64_t* b, size_t nkeys, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
