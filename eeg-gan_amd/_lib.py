@@ -73,6 +73,12 @@ SIGNATURES = {
     "eeggan_swd_sort": (_i, [C.c_void_p, C.c_void_p, _sz, _i, C.c_void_p, _sz, _st]),
     "eeggan_swd_distance_workspace": (_sz, []),
     "eeggan_swd_distance": (_i, [C.c_void_p, C.c_void_p, _sz, _f, C.c_void_p, _sz, _st]),
+    "eeggan_cpc_encoder": (_i, [_f] * 13 + [_i, _i, _i, _st]),
+    "eeggan_pnorm_pool": (_i, [_f, _f, _i, _i, _i, _st]),
+    "eeggan_dense": (_i, [_f, _f, _f, _f, _f, _f, _sz, _i, _i, _sz, _sz, _i, _fl, _fl, _i, _st]),
+    "eeggan_gru_forward": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
+    "eeggan_feature_stats_workspace": (_sz, [_sz, _i]),
+    "eeggan_feature_stats": (_i, [_f, _sz, _i, _f, _f, C.c_void_p, _sz, _st]),
     "eeggan_adam_step": (_i, [C.c_void_p, _i, _fl, _fl, _fl, _fl, _fl, _st]),
     "eeggan_multi_copy": (_i, [C.c_void_p, _i, _st]),
 }

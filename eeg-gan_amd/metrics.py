@@ -152,3 +152,145 @@ class SlicedWDistance(Plugin):
             swd.append(np.array(swd).mean())
         self.trainer.stats["swd"]["val"] = swd
         self.trainer.stats["swd"]["epoch"] = epoch_index
+
+
+class FidCalculator(Plugin):
+    """Frechet distance between CPC features of generated and of real signals (reference plugins.py:454-648).
+
+    The statistics (``torch_cov``, ``sqrt_newton_schulz``, ``torch_calculate_frechet_distance``, ``calc_fid``)
+    keep the reference's names and arithmetic and run on the device.  ``epoch`` follows the reference's flow
+    with the calls its feature network actually offers (the reference plugin at HEAD still calls a constructor
+    signature and an ``inference_forward`` method its network no longer has, plugins.py:469-477, 589)."""
+
+    def __init__(self, num_channels, create_dataloader_fun, target_seq_len, num_samples=1024 * 16,
+                 output_snapshot_ticks=25, calc_for_z=True, calc_for_zp=True, calc_for_c=True, calc_for_cp=True,
+                 network=None):
+        super().__init__([(1, "epoch")])
+        from .cpc import Network
+        self.create_dataloader_fun = create_dataloader_fun
+        self.output_snapshot_ticks = output_snapshot_ticks
+        self.last_depth = -1
+        self.last_alpha = -1
+        self.target_seq_len = target_seq_len
+        self.calc_z, self.calc_zp, self.calc_c, self.calc_cp = calc_for_z, calc_for_zp, calc_for_c, calc_for_cp
+        self.num_samples = num_samples
+        self.network = cudize(network if network is not None else Network(num_channels)).eval()
+        self.real_stats = {}
+
+    def register(self, trainer):
+        self.trainer = trainer
+        fields, dd = [], {"epoch": 0}
+        for flag, key in ((self.calc_c, "c_fake"), (self.calc_z, "z_fake"), (self.calc_cp, "cp_fake"),
+                          (self.calc_zp, "zp_fake")):
+            if flag:
+                fields.append("{" + key + ":.2f}")
+                dd[key] = float("nan")
+        fields.append("{epoch:.2f}")
+        self.trainer.stats["FID"] = {"log_name": "FID", "log_epoch_fields": fields, **dd}
+
+    # ---- statistics ------------------------------------------------------------------------------------
+    @staticmethod
+    def mean_and_cov(m):
+        """(column means, unbiased covariance of the columns) of a feature matrix [N, F], one pass over it."""
+        m = _dev_f32(m, "mean_and_cov m")
+        N, F = m.shape
+        lib = _lib.load()
+        nbytes = lib.eeggan_feature_stats_workspace(N, F)
+        ws = torch.empty(nbytes, device=m.device, dtype=torch.uint8)
+        mean = torch.empty(F, device=m.device, dtype=torch.float32)
+        cov = torch.empty((F, F), device=m.device, dtype=torch.float32)
+        call("eeggan_feature_stats", m.data_ptr(), N, F, mean.data_ptr(), cov.data_ptr(), ws.data_ptr(), nbytes, _stream())
+        return mean, cov
+
+    @staticmethod
+    def torch_cov(m, rowvar=False):
+        if m.dim() > 2:
+            raise ValueError("m has more than 2 dimensions")
+        if m.dim() < 2:
+            m = m.view(1, -1)
+        if rowvar and m.size(0) != 1:
+            m = m.t()
+        return FidCalculator.mean_and_cov(m)[1]
+
+    @staticmethod
+    def sqrt_newton_schulz(A, numIters, dtype=None):
+        """Matrix square root of A [batch, n, n] by the coupled Newton-Schulz iteration (plugins.py:540-555)."""
+        from .cpc import dense
+        A = _dev_f32(A, "sqrt_newton_schulz A")
+        if A.dim() != 3 or A.shape[1] != A.shape[2]:
+            raise RuntimeError("sqrt_newton_schulz: expected [batch, n, n]")
+        out = torch.empty_like(A)
+        for b in range(A.shape[0]):
+            a = A[b]
+            norm = a.mul(a).sum().sqrt()  # (one scalar of glue on an n x n matrix)
+            n = a.shape[0]
+            Y = (a / norm).contiguous()
+            Z = torch.eye(n, device=a.device, dtype=torch.float32)
+            for _ in range(numIters):
+                T = dense(Z, Y, w_is_kn=True, alpha=-0.5, eye=1.5)  # 0.5 (3 I - Z Y)
+                Y = dense(Y, T, w_is_kn=True)
+                Z = dense(T, Z, w_is_kn=True)
+            out[b] = Y * torch.sqrt(norm)
+        return out
+
+    @staticmethod
+    def torch_calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+        from .cpc import dense
+        assert mu1.shape == mu2.shape, "Training and test mean vectors have different lengths"
+        assert sigma1.shape == sigma2.shape, "Training and test covariances have different dimensions"
+        diff = mu1 - mu2
+        prod = dense(_dev_f32(sigma1, "sigma1"), _dev_f32(sigma2, "sigma2"), w_is_kn=True)
+        covmean = FidCalculator.sqrt_newton_schulz(prod.unsqueeze(0), 50).squeeze(0)
+        return diff.dot(diff) + torch.trace(sigma1) + torch.trace(sigma2) - 2 * torch.trace(covmean)
+
+    @staticmethod
+    def calc_fid(mu1, std1, mu2, std2):
+        fid = FidCalculator.torch_calculate_frechet_distance(mu1, std1, mu2, std2).item()
+        if fid != fid:
+            raise FloatingPointError("the Newton-Schulz iteration did not converge (the reference falls back to a "
+                                     "host eigen-decomposition here, plugins.py:560-562)")
+        return fid
+
+    # ---- features --------------------------------------------------------------------------------------
+    def features(self, x):
+        """The four feature matrices of a batch, shaped as the reference shapes them before its statistics
+        (plugins.py:590-597): z and c as rows of 128 numbers read straight from [B, 128, T] memory."""
+        from .utils import resample_signal
+        x = resample_signal(x, x.size(2), self.target_seq_len, True)
+        lat = self.network(x, no_loss=True).latents
+        return {"z": lat.z.reshape(-1, lat.z.size(1)), "c": lat.c.contiguous().view(-1, lat.c.size(1)),
+                "zp": lat.z_p, "cp": lat.c_p}
+
+    def _stats_of(self, batches):
+        """Mean and covariance per feature kind over a stream of input batches (at least num_samples samples)."""
+        kinds = [k for k, on in (("z", self.calc_z), ("c", self.calc_c), ("zp", self.calc_zp), ("cp", self.calc_cp)) if on]
+        parts = {k: [] for k in kinds}
+        seen = 0
+        with torch.no_grad():
+            for x in batches:
+                feats = self.features(x)
+                for k in kinds:
+                    parts[k].append(feats[k])
+                seen += x.size(0)
+                if seen >= self.num_samples:
+                    break
+        return {k: self.mean_and_cov(torch.cat(v, dim=0)) for k, v in parts.items()}
+
+    def epoch(self, epoch_index):
+        if epoch_index % self.output_snapshot_ticks != 0:
+            return
+        tr = self.trainer
+        if not (self.last_depth == tr.dataset.model_depth and self.last_alpha == tr.dataset.alpha):
+            loader = self.create_dataloader_fun(min(tr.stats["minibatch_size"], 1024), False, tr.dataset.model_depth,
+                                                tr.dataset.alpha)
+            self.real_stats = self._stats_of(cudize(data["x"]) for data in loader)
+            self.last_depth, self.last_alpha = tr.dataset.model_depth, tr.dataset.alpha
+
+        def fakes():
+            while True:
+                yield tr.generator(cudize(next(tr.random_latents_generator)))[0]["x"]
+
+        fake_stats = self._stats_of(fakes())
+        for k, (mu, cov) in fake_stats.items():
+            tr.stats["FID"][k + "_fake"] = self.calc_fid(mu, cov, *self.real_stats[k])
+        tr.stats["FID"]["epoch"] = epoch_index

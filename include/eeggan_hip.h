@@ -276,6 +276,36 @@ size_t eeggan_swd_distance_workspace(void);
 int eeggan_swd_distance(const uint64_t* a, const uint64_t* b, size_t nkeys, float* out, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- CPC feature network, inference (cpc/cpc_network.py) and Frechet-distance statistics (plugins.py:503-572)
+ * eeggan_cpc_encoder: ConvEncoder in eval mode (cpc_network.py:137-158 with its defaults: 32/64/128 channels,
+ *   strides 5/4/3, kernels 9/7/5, padding (k-1)/2; ReLU, dropout off, BatchNorm1d after the first two layers as
+ *   the per-channel scale/shift of its running statistics; s1/t1, s2/t2 NULL = no normalisation):
+ *     h1 = s1 * relu(conv(x, w1) + b1) + t1;  h2 = s2 * relu(conv(h1, w2) + b2) + t2;  z = relu(conv(h2, w3) + b3)
+ *   x [B, Cin, T], T a multiple of 60; weights TRANSPOSED: wNt[(ci*K + j)*Cout + co] = wN[co, ci, j];
+ *   z [B, 128, T/60]; zt (may be NULL) the same codes time-major, [B, T/60, 128].
+ * eeggan_pnorm_pool: out[b, c] = sum_t |x[b,c,t]|, out[b, C + c] = max_t |x[b,c,t]|  (PNormPooling.forward with
+ *   p = [1, inf], cpc_network.py:185-188, before its MLP).
+ * eeggan_dense: y[n, m] = shift[m] + scale[m] * act(bias[m] + alpha * sum_k x[n*ldx + k] * W(m, k)) + eye * (n == m)
+ *   with W(m, k) = w[m*K + k] (nn.Linear, cpc_network.py:178) or w[k*M + m] when w_is_kn (a plain product x w:
+ *   the bmm calls of sqrt_newton_schulz, plugins.py:551-553); act = ReLU when relu != 0; bias, scale/shift
+ *   may be NULL (a following eval-mode BatchNorm1d is scale/shift, cpc_network.py:181-182).
+ * eeggan_gru_forward: torch.nn.GRU(128, 128), one layer, h0 = 0 (cpc_network.py:203, 211-216) given the input
+ *   projections gi[(b*T + t)*384 + g*128 + j] = (W_ih x_t + b_ih)[g*128 + j]; writes c[b, j, t] = h_t[b, j].
+ * eeggan_feature_stats: mean[f] and the unbiased covariance cov[f, g] of the rows of X[N, F]
+ *   (FidCalculator.torch_cov with rowvar=False, plugins.py:503-514); sums in a fixed order, partials in double. */
+int eeggan_cpc_encoder(const float* x, const float* w1t, const float* b1, const float* s1, const float* t1,
+                       const float* w2t, const float* b2, const float* s2, const float* t2, const float* w3t,
+                       const float* b3, float* z, float* zt, int B, int Cin, int T, void* stream);
+int eeggan_pnorm_pool(const float* x, float* out, int B, int C, int T, void* stream);
+int eeggan_dense(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                 float* y, size_t N, int K, int M, size_t ldx, size_t ldy, int w_is_kn, float alpha, float eye,
+                 int relu, void* stream);
+int eeggan_gru_forward(const float* gi, const float* whh, const float* bhh, float* c, int B, int H, int T,
+                       void* stream);
+size_t eeggan_feature_stats_workspace(size_t N, int F);
+int eeggan_feature_stats(const float* X, size_t N, int F, float* mean, float* cov, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,87 @@ def swd_get_descriptors(batch1: torch.Tensor, batch2: torch.Tensor, progression_
         descs = [swd_descriptors(batch, b, patches_per_item, patch_size) for batch in (batch1, batch2)]
         out.append(swd_sliced_wasserstein(descs[0], descs[1], dir_repeats, dirs_per_repeat))
     return out
+
+
+# --------------------------------------------------------------------------- CPC feature network, inference
+def cpc_conv_encoder(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix: str = "encoder.") -> torch.Tensor:
+    """cpc_network.py:137-158 in eval mode: three strided convs (kernel 2s-1, padding s-1 for s = 5, 4, 3), each
+    followed by ReLU, the first two also by (inactive) dropout and BatchNorm1d on its running statistics."""
+    h = x
+    for conv_i, bn_i, stride in ((0, 3, 5), (4, 7, 4), (8, None, 3)):
+        w, b = sd[f"{prefix}{conv_i}.weight"], sd[f"{prefix}{conv_i}.bias"]
+        h = F.relu(F.conv1d(h, w, b, stride=stride, padding=(w.shape[2] - 1) // 2))
+        if bn_i is not None:
+            h = F.batch_norm(h, sd[f"{prefix}{bn_i}.running_mean"], sd[f"{prefix}{bn_i}.running_var"],
+                             sd[f"{prefix}{bn_i}.weight"], sd[f"{prefix}{bn_i}.bias"], training=False, eps=1e-5)
+    return h
+
+
+def cpc_pnorm_pool(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix: str) -> torch.Tensor:
+    """cpc_network.py:161-188 with p = [1, inf]: the two norms over time, concatenated, through
+    Linear -> ReLU -> [BatchNorm1d (eval)] -> Linear.  The normalisation is there for the z pooler only: the
+    network passes False in its place for the c pooler (cpc_network.py:296)."""
+    n = torch.cat([x.abs().sum(dim=2), x.abs().amax(dim=2)], dim=1)
+    h = F.relu(F.linear(n, sd[f"{prefix}network.0.weight"], sd[f"{prefix}network.0.bias"]))
+    last = 2
+    if f"{prefix}network.2.running_mean" in sd:
+        h = F.batch_norm(h, sd[f"{prefix}network.2.running_mean"], sd[f"{prefix}network.2.running_var"],
+                         sd[f"{prefix}network.2.weight"], sd[f"{prefix}network.2.bias"], training=False, eps=1e-5)
+        last = 3
+    return F.linear(h, sd[f"{prefix}network.{last}.weight"], sd[f"{prefix}network.{last}.bias"])
+
+
+def cpc_gru(sd: Dict[str, torch.Tensor], x: torch.Tensor, prefix: str = "contextualizer.forward_rnn.") -> torch.Tensor:
+    """cpc_network.py:191-216: one-layer GRU over time from a zero state (torch.nn.GRU's equations written
+    out), input and output [B, C, T]."""
+    w_ih, w_hh = sd[prefix + "weight_ih_l0"], sd[prefix + "weight_hh_l0"]
+    b_ih, b_hh = sd[prefix + "bias_ih_l0"], sd[prefix + "bias_hh_l0"]
+    B, C, T = x.shape
+    H = w_hh.shape[1]
+    h = torch.zeros(B, H, dtype=x.dtype)
+    out = []
+    for t in range(T):
+        gi = F.linear(x[:, :, t], w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        out.append(h)
+    return torch.stack(out, dim=2)
+
+
+def cpc_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor):
+    """Network.forward(x, no_loss=True), cpc_network.py:316-322: (z, c, z_pooled, c_pooled)."""
+    z = cpc_conv_encoder(sd, x)
+    z_p = cpc_pnorm_pool(sd, z, "z_pooler.")
+    c = cpc_gru(sd, z)
+    c_p = cpc_pnorm_pool(sd, c, "c_pooler.")
+    return z, c, z_p, c_p
+
+
+# --------------------------------------------------------------------------- Frechet distance
+def torch_cov(m: torch.Tensor) -> torch.Tensor:
+    """plugins.py:503-514 with rowvar=False: unbiased covariance of the columns of m [N, F]."""
+    m = m.t()
+    m = m - torch.mean(m, dim=1, keepdim=True)
+    return (1.0 / (m.size(1) - 1)) * m.matmul(m.t())
+
+
+def sqrt_newton_schulz(A: torch.Tensor, iters: int) -> torch.Tensor:
+    """plugins.py:540-555 for one matrix."""
+    n = A.shape[0]
+    norm = A.mul(A).sum().sqrt()
+    Y, eye, Z = A / norm, torch.eye(n, dtype=A.dtype), torch.eye(n, dtype=A.dtype)
+    for _ in range(iters):
+        T = 0.5 * (3.0 * eye - Z.mm(Y))
+        Y = Y.mm(T)
+        Z = T.mm(Z)
+    return Y * torch.sqrt(norm)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2) -> torch.Tensor:
+    """plugins.py:565-572."""
+    diff = mu1 - mu2
+    covmean = sqrt_newton_schulz(sigma1.mm(sigma2), 50)
+    return diff.dot(diff) + torch.trace(sigma1) + torch.trace(sigma2) - 2 * torch.trace(covmean)

@@ -105,3 +105,120 @@ def test_swd_full_size_properties(dev):
     torch.manual_seed(2)
     ba = plugin.sliced_wasserstein(db, da)
     assert ab > 0 and ab == ba
+
+
+# ---------------------------------------------------------------------------------------------- CPC features, FID
+def _cpc_network(fx):
+    """This package's mirror of the reference's feature network in the state the fixture was made with: same
+    seed (same initial weights, checked by their checksums) and the same seeded BatchNorm state."""
+    from eeggan_amd import cpc
+    torch.manual_seed(int(fx["cpc_seed"]))
+    net = cpc.Network(5).eval()
+    gen = torch.Generator().manual_seed(int(fx["cpc_norm_seed"]))
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            n = m.num_features
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(n, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(n, generator=gen) + 0.5)
+                m.weight.copy_(torch.rand(n, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(n, generator=gen) * 0.2)
+    got = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in net.state_dict().values()
+                    if v.is_floating_point()])
+    np.testing.assert_allclose(got, fx["cpc_check"], rtol=1e-5, atol=1e-3,
+                               err_msg="the feature network's initial state differs from the reference's")
+    return net
+
+
+def test_oracle_cpc_and_fid_match_reference():
+    from oracle import metrics_cpu as M
+    fx = load_fixture("metrics")
+    net = _cpc_network(fx)
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()}
+    got = M.cpc_forward(sd, torch.from_numpy(fx["cpc_x"]).double())
+    for a, name in zip(got, ("z", "c", "zp", "cp")):
+        assert rel(a, fx[f"cpc_{name}64"]) < 1e-6, name  # (weights re-drawn here: ~1 ulp of the fp32 init per element)
+    a, b = torch.from_numpy(fx["fid_a"]).double(), torch.from_numpy(fx["fid_b"]).double()
+    s1, s2 = M.torch_cov(a), M.torch_cov(b)
+    assert rel(s1, fx["fid_cov64"]) < 1e-12
+    assert rel(M.sqrt_newton_schulz(s1.mm(s2), 50), fx["fid_root64"]) < 1e-9
+    fid = float(M.frechet_distance(a.mean(0), s1, b.mean(0), s2))
+    assert abs(fid - float(fx["fid_value64"])) < 1e-9 * abs(fid)
+
+
+def test_cpc_mirror_rejects_what_it_does_not_run():
+    from eeggan_amd import cpc
+    with pytest.raises(NotImplementedError):
+        cpc.Network(5, use_transformer=True)
+    with pytest.raises(NotImplementedError):
+        cpc.Network(5, residual_encoder=True)
+    net = cpc.Network(5)
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 5, 1920), no_loss=False)
+    assert set(k.split(".")[0] for k in net.state_dict()) == {"encoder", "z_pooler", "contextualizer", "c_pooler"}
+
+
+@pytest.mark.gpu
+def test_cpc_network_against_reference(dev):
+    """Network.forward(x, no_loss=True) (reference cpc_network.py:316-322) on the device against the reference's
+    latents: 1e-4 relative (fp32; measured far below)."""
+    fx = load_fixture("metrics")
+    net = _cpc_network(fx).to(dev)
+    x = torch.from_numpy(fx["cpc_x"]).to(dev)
+    with torch.no_grad():
+        lat = net(x, no_loss=True).latents
+    for got, name in zip(lat, ("z", "c", "zp", "cp")):
+        e = min(rel(got, fx[f"cpc_{name}64"]), rel(got, fx[f"cpc_{name}32"]))
+        print(f"cpc latent {name}: {e:.2e}")
+        assert tuple(got.shape) == fx[f"cpc_{name}64"].shape
+        assert e < 1e-4, (name, e)
+    # a batch that does not fill the last workgroup of the recurrence, and a shorter window
+    from oracle import metrics_cpu as M
+    sd = {k: (v.detach().double().cpu() if v.is_floating_point() else v.cpu()) for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(2)
+    for shape in ((37, 5, 1920), (3, 5, 960)):
+        xs = torch.tanh(torch.randn(*shape, generator=gen))
+        with torch.no_grad():
+            lat = net(xs.to(dev), no_loss=True).latents
+        for got, want, name in zip(lat, M.cpc_forward(sd, xs.double()), ("z", "c", "zp", "cp")):
+            assert rel(got, want) < 1e-4, (shape, name, rel(got, want))
+
+
+@pytest.mark.gpu
+def test_dense_kernel(dev):
+    from eeggan_amd.cpc import dense
+    gen = torch.Generator().manual_seed(6)
+    for N, K, M in ((100, 128, 384), (7, 20, 5), (65, 256, 128), (64, 64, 64)):
+        x, w, b = torch.randn(N, K, generator=gen), torch.randn(M, K, generator=gen), torch.randn(M, generator=gen)
+        sc, sh = torch.rand(M, generator=gen) + 0.5, torch.randn(M, generator=gen)
+        ref = torch.relu(x.double() @ w.double().T + b.double()) * sc.double() + sh.double()
+        got = dense(x.to(dev), w.to(dev), b.to(dev), sc.to(dev), sh.to(dev), relu=True)
+        assert rel(got, ref) < 2e-6, (N, K, M)
+        if N == M == K:
+            ref = -0.5 * (x.double() @ w.double()) + 1.5 * torch.eye(N, dtype=torch.float64)
+            assert rel(dense(x.to(dev), w.to(dev), w_is_kn=True, alpha=-0.5, eye=1.5), ref) < 2e-6
+
+
+@pytest.mark.gpu
+def test_fid_statistics_against_reference(dev):
+    """Covariance, Newton-Schulz square root and the Frechet distance (reference plugins.py:503-572)."""
+    from eeggan_amd.plugins import FidCalculator
+    fx = load_fixture("metrics")
+    a, b = torch.from_numpy(fx["fid_a"]).to(dev), torch.from_numpy(fx["fid_b"]).to(dev)
+    mu1, s1 = FidCalculator.mean_and_cov(a)
+    mu2, s2 = FidCalculator.mean_and_cov(b)
+    assert rel(s1, fx["fid_cov64"]) < 1e-5 and rel(mu1, fx["fid_a"].mean(0)) < 1e-6
+    assert rel(FidCalculator.torch_cov(a.t().contiguous(), rowvar=True), fx["fid_cov64"]) < 1e-5
+    from eeggan_amd.cpc import dense
+    root = FidCalculator.sqrt_newton_schulz(dense(s1, s2, w_is_kn=True).unsqueeze(0), 50).squeeze(0)
+    e = min(rel(root, fx["fid_root64"]), rel(root, fx["fid_root32"]))
+    assert e < 1e-3, e  # fifty fp32 iterations: the reference's own fp32 run is this far from its fp64 run
+    fid = FidCalculator.calc_fid(mu1, s1, mu2, s2)
+    ref64, ref32 = float(fx["fid_value64"]), float(fx["fid_value32"])
+    assert min(abs(fid - ref64), abs(fid - ref32)) < 1e-4 * abs(ref64), (fid, ref64, ref32)
+    # many rows: several partial blocks, a last block that is not full
+    gen = torch.Generator().manual_seed(1)
+    big = torch.randn(10000, 128, generator=gen) * torch.rand(128, generator=gen) + torch.randn(128, generator=gen)
+    mu, cov = FidCalculator.mean_and_cov(big.to(dev))
+    assert rel(mu, big.double().mean(0)) < 1e-5
+    assert rel(cov, torch.cov(big.double().T)) < 1e-5

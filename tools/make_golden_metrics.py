@@ -76,12 +76,87 @@ def swd_fixture(fx):
     print("swd: reference", ref, "oracle", mine)
 
 
+def randomize_norms(net, seed):
+    """Non-trivial BatchNorm state (running statistics and affine parameters), drawn from a seed: the same call
+    on this package's mirror of the network gives it the same state."""
+    gen = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            n = m.num_features
+            with torch.no_grad():
+                m.running_mean.copy_(torch.randn(n, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(n, generator=gen) + 0.5)
+                m.weight.copy_(torch.rand(n, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(n, generator=gen) * 0.2)
+
+
+def cpc_fixture(fx):
+    sys.path.insert(0, REPO)
+    from eeggan_amd import cpc as my_cpc
+    seed = 21
+    torch.manual_seed(seed)
+    ref = ref_cpc.Network(5).eval()
+    torch.manual_seed(seed)
+    mine = my_cpc.Network(5).eval()
+    randomize_norms(ref, 3)
+    randomize_norms(mine, 3)
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    for k, v in sd_mine.items():
+        assert torch.equal(v, sd_ref[k]), f"{k}: the mirror's initial state differs from the reference's"
+    gen = torch.Generator().manual_seed(4)
+    x = torch.tanh(torch.randn(6, 5, 1920, generator=gen).cumsum(dim=2) * 0.05)
+    with torch.no_grad():
+        lat64 = ref.double()(x.double(), no_loss=True).latents
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in ref.state_dict().items()}
+        got = M.cpc_forward(sd64, x.double())
+        for a, b, name in zip(got, lat64, ("z", "c", "z_p", "c_p")):
+            assert rel(a, b) < 1e-12, (name, rel(a, b))
+        lat32 = ref.float()(x, no_loss=True).latents
+    fx.update(cpc_seed=np.array(seed), cpc_norm_seed=np.array(3), cpc_x=x.numpy(),
+              cpc_check=np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd_mine.values()
+                                  if v.is_floating_point()]))
+    for name, a, b in zip(("z", "c", "zp", "cp"), lat64, lat32):
+        fx[f"cpc_{name}64"], fx[f"cpc_{name}32"] = a.numpy(), b.numpy()
+    print("cpc: latents", [tuple(v.shape) for v in lat64])
+
+
+def fid_fixture(fx):
+    gen = torch.Generator().manual_seed(8)
+    N, Fdim = 400, 64
+    mix1, mix2 = torch.randn(Fdim, Fdim, generator=gen) * 0.3, torch.randn(Fdim, Fdim, generator=gen) * 0.3
+    a = torch.relu(torch.randn(N, Fdim, generator=gen) @ mix1 + 0.2)
+    b = torch.relu(torch.randn(N, Fdim, generator=gen) @ mix2 + 0.1)
+    F_ = ref_plugins.FidCalculator
+    out = {}
+    for dt, tag in ((torch.float64, "64"), (torch.float32, "32")):
+        a_, b_ = a.to(dt), b.to(dt)
+        mu1, mu2 = a_.mean(0), b_.mean(0)
+        s1, s2 = F_.torch_cov(a_.clone(), rowvar=False), F_.torch_cov(b_.clone(), rowvar=False)
+        root = F_.sqrt_newton_schulz(s1.mm(s2).unsqueeze(0), 50, dtype=a_.type()).squeeze()
+        fid = F_.torch_calculate_frechet_distance(mu1, s1, mu2, s2)
+        out[tag] = (s1, root, fid)
+    s1, root, fid = out["64"]
+    assert rel(M.torch_cov(a.double()), s1) < 1e-12
+    assert rel(M.sqrt_newton_schulz(s1.mm(M.torch_cov(b.double())), 50), root) < 1e-9
+    assert abs(float(M.frechet_distance(a.double().mean(0), s1, b.double().mean(0), M.torch_cov(b.double()))) - float(fid)) < 1e-9
+    fx.update(fid_a=a.numpy(), fid_b=b.numpy(), fid_cov64=s1.numpy(), fid_root64=root.numpy(), fid_value64=np.array(float(fid)),
+              fid_value32=np.array(float(out["32"][2])), fid_root32=out["32"][1].numpy())
+    print("fid: reference", float(fid), "(fp32:", float(out["32"][2]), ")")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     args = ap.parse_args()
     fx = {}
     swd_fixture(fx)
+    cpc_fixture(fx)
+    fid_fixture(fx)
     np.savez_compressed(os.path.join(args.out, "metrics.npz"), **fx)
     print("metrics.npz:", len(fx), "arrays")
 
