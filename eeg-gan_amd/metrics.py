@@ -34,6 +34,8 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class SlicedWDistance(Plugin):
+    MAX_SORT_KEYS = 1 << 30  # keys per sort (8 bytes each)
+
     def __init__(self, progression_scale: int, output_snapshot_ticks: int, patches_per_item: int = 16,
                  patch_size: int = 49, max_items: int = 1024, number_of_projections: int = 512,
                  dir_repeats: int = 4, dirs_per_repeat: int = 128):
@@ -75,15 +77,22 @@ class SlicedWDistance(Plugin):
         lib = _lib.load()
         nbytes = lib.eeggan_swd_distance_workspace()
         ws = torch.empty(nbytes, device=A.device, dtype=torch.uint8)
-        results = torch.empty(self.dir_repeats, device=A.device, dtype=torch.float32)
+        # directions are taken in chunks so that one sort holds at most MAX_SORT_KEYS keys (four key buffers and
+        # the sort's workspace are alive at once); a chunk's mean enters with the share of the directions it holds
+        chunk = max(1, min(self.dirs_per_repeat, self.MAX_SORT_KEYS // max(1, A.shape[0])))
+        spans = [(lo, min(lo + chunk, self.dirs_per_repeat)) for lo in range(0, self.dirs_per_repeat, chunk)]
+        results = torch.empty((self.dir_repeats, len(spans)), device=A.device, dtype=torch.float32)
         for repeat in range(self.dir_repeats):
             dirs = torch.randn(A.shape[1], self.dirs_per_repeat)  # host generator, like the reference
             dirs /= torch.sqrt((dirs * dirs).sum(dim=0, keepdim=True) + EPSILON)
-            dirs = dirs.contiguous().to(A.device)
-            ka, kb = self._sorted_projections(A, dirs), self._sorted_projections(B, dirs)
-            call("eeggan_swd_distance", ka.data_ptr(), kb.data_ptr(), ka.numel(), results[repeat:].data_ptr(),
-                 ws.data_ptr(), nbytes, _stream())
-        return float(results.double().mean().item())
+            for j, (lo, hi) in enumerate(spans):
+                part = dirs[:, lo:hi].contiguous().to(A.device)
+                ka, kb = self._sorted_projections(A, part), self._sorted_projections(B, part)
+                call("eeggan_swd_distance", ka.data_ptr(), kb.data_ptr(), ka.numel(), results[repeat, j:].data_ptr(),
+                     ws.data_ptr(), nbytes, _stream())
+                del ka, kb
+        weights = torch.tensor([(hi - lo) / self.dirs_per_repeat for lo, hi in spans], dtype=torch.float64)
+        return float((results.double().cpu() * weights).sum(dim=1).mean().item())
 
     def _descriptors(self, batch: torch.Tensor, items: int, step: int = 1) -> torch.Tensor:
         """Normalised patch descriptors of ``batch[:, :, ::step]``: [items * patches_per_item * patch_size, c]."""
@@ -244,11 +253,27 @@ class FidCalculator(Plugin):
         return diff.dot(diff) + torch.trace(sigma1) + torch.trace(sigma2) - 2 * torch.trace(covmean)
 
     @staticmethod
+    def eig_calculate_frechet_distance(mu1, sigma1, mu2, sigma2):
+        """The distance with tr sqrt(sigma1 sigma2) taken from eigenvalues, in fp64 on the device: the eigenvalues
+        of sigma1 sigma2 are those of the symmetric r sigma2 r with r = sqrt(sigma1), so the trace of the principal
+        square root is the sum of their roots.  It stands where the reference leaves the Newton-Schulz iteration
+        for a host ``scipy.linalg.sqrtm`` of the product (plugins.py:517-537, 560-562) and gives that result
+        without the detour over the host; it does not break down on singular covariances."""
+        s1, s2 = sigma1.double(), sigma2.double()
+        w, v = torch.linalg.eigh(0.5 * (s1 + s1.t()))
+        r = (v * w.clamp_min(0).sqrt()) @ v.t()
+        m = r @ s2 @ r
+        lam = torch.linalg.eigvalsh(0.5 * (m + m.t())).clamp_min(0)
+        diff = (mu1 - mu2).double()
+        return diff.dot(diff) + torch.trace(s1) + torch.trace(s2) - 2 * lam.sqrt().sum()
+
+    @staticmethod
     def calc_fid(mu1, std1, mu2, std2):
+        """Newton-Schulz first; when it does not converge (NaN: an ill-conditioned product in fp32), the
+        eigenvalue form, as the reference then switches to its second method (plugins.py:558-563)."""
         fid = FidCalculator.torch_calculate_frechet_distance(mu1, std1, mu2, std2).item()
         if fid != fid:
-            raise FloatingPointError("the Newton-Schulz iteration did not converge (the reference falls back to a "
-                                     "host eigen-decomposition here, plugins.py:560-562)")
+            fid = FidCalculator.eig_calculate_frechet_distance(mu1, std1, mu2, std2).item()
         return fid
 
     # ---- features --------------------------------------------------------------------------------------

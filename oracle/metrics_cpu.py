@@ -159,3 +159,21 @@ def frechet_distance(mu1, sigma1, mu2, sigma2) -> torch.Tensor:
     diff = mu1 - mu2
     covmean = sqrt_newton_schulz(sigma1.mm(sigma2), 50)
     return diff.dot(diff) + torch.trace(sigma1) + torch.trace(sigma2) - 2 * torch.trace(covmean)
+
+
+def numpy_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """The reference's second method (plugins.py:517-537): scipy's sqrtm of the covariance product on the host,
+    with its retry on a non-finite root and its treatment of a complex result."""
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(np.asarray(mu1, dtype=np.float64)), np.atleast_1d(np.asarray(mu2, dtype=np.float64))
+    sigma1, sigma2 = np.atleast_2d(np.asarray(sigma1, dtype=np.float64)), np.atleast_2d(np.asarray(sigma2, dtype=np.float64))
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-1):
+            raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
