@@ -48,7 +48,7 @@ class GraphedCall:
 
 
 class _SplitCriticIteration:
-    """One critic iteration as THREE captured graphs instead of one.
+    """One critic iteration as several single-chain captured graphs instead of one.
 
     The critic loss is a sum of a term of the stacked [reals; fakes] pass alone and a term of the
     interpolates' pass alone (``losses.discriminator_loss(part=...)``), so the two passes -- forward and
@@ -57,20 +57,23 @@ class _SplitCriticIteration:
 
         graph A (launch stream): stacked pass, its loss term, its backward; weight-gradient slabs only
         graph B (side stream)  : interpolates' pass, create_graph input gradient, penalty, double backward
-        graph C (launch stream, behind both): slab sums of A and B, loss sum, [bucket pack | Adam + new
-                                 flipped weight views for the next iteration]
+        closing graphs (launch stream, behind both): sums over the chains of the gradients autograd
+                                 accumulated; slab sums of A and B, loss sum, [Adam + new flipped weight views for
+                                 the next iteration | data-parallel: one gradient bucket per closing graph, each
+                                 with its all-reduce started right behind it and its Adam in a graph of its own]
 
     (``parts`` names the chains; the score term can be split once more into a reals' and a fakes' chain.)
     Every graph is a single chain captured on one stream; the chains are replayed on real streams of their
     own and ordered by ordinary stream waits.  (One captured graph with two parallel branches was measured first: on
     ROCm 7.2 its origin-stream branch started before earlier work of the launch stream had finished.)"""
 
+    serial = False  # replay the chains one after the other on the launch stream (comparison runs)
+
     def __init__(self, trainer, d_loss_fn, sync, bucketed, warmup=3, parts=("scores", "penalty")):
         self.trainer, self.sync, self.bucketed = trainer, sync, bucketed
         dis, gen, opt = trainer.discriminator, trainer.generator, trainer.optimizer_d
         self.parts = tuple(parts)
         self.sides = [torch.cuda.Stream() for _ in self.parts[1:]]  # default priority
-        self.bucket = None
 
         def chain(part):
             loss = d_loss_fn(dis, gen, {"x": trainer._real}, {"z": trainer._z}, part=part,
@@ -83,31 +86,56 @@ class _SplitCriticIteration:
                 p.grad = None
             return loss.detach(), stash
 
-        def close(results):
-            ops.flush_direct_grads()  # slab sums of all chains -> p.grad of the conv weights
+        def close_early(results):
+            """Gradients that are complete once the chains are (autograd's route: the full-length layer, the
+            linear layer): summed over the chains and, data-parallel, packed into a bucket of their own."""
             grads = {}
             for _, stash in results:
                 for p, g in stash:
                     grads[p] = g if p not in grads else grads[p] + g
             for p, g in grads.items():
                 p.grad = g
+            early = list(grads)
+            if bucketed and early:
+                self.bucket_early = sync.pack(dis, params=early, slot="early")
+            return early
+
+        def close_late(results, early):
+            """Slab sums of all chains -> p.grad of the conv weights, the loss, and [their bucket | Adam + new
+            flipped weight views]."""
+            ops.flush_direct_grads()
             loss = results[0][0]
             for other, _ in results[1:]:
                 loss = loss + other
             if bucketed:
-                self.bucket = sync.pack(dis)
+                taken = {id(p) for p in early}
+                late = [p for p in dis.parameters() if p.grad is not None and id(p) not in taken]
+                if late:
+                    self.bucket_late = sync.pack(dis, params=late, slot="late")
             else:
                 self._step(opt, dis)
             return loss
 
+        def apply_early():
+            if self.bucket_early is not None:
+                sync.apply(opt, self.bucket_early)
+
+        def apply_late():
+            if self.bucket_late is not None:
+                sync.apply(opt, self.bucket_late)
+            ops.refresh_flipped_weights(dis)  # for the next iteration's chains
+
+        self.bucket_early = self.bucket_late = None
         cur = torch.cuda.current_stream()
         warm = torch.cuda.Stream()
         warm.wait_stream(cur)
         with torch.cuda.stream(warm):
             for _ in range(warmup):
-                close([chain(part) for part in self.parts])
+                results = [chain(part) for part in self.parts]
+                close_late(results, close_early(results))
                 if bucketed:
-                    self._step(opt, dis, grads=self.bucket)
+                    apply_early()
+                    apply_late()
         cur.wait_stream(warm)
         torch.cuda.synchronize()
         # the chains read the flipped weight views the closing graph of the previous iteration has built
@@ -120,34 +148,57 @@ class _SplitCriticIteration:
             for graph, part in zip(self.graphs, self.parts):
                 with torch.cuda.graph(graph):
                     results.append(chain(part))
-            self.graph_c = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_c):
-                self.out = close(results)
+            # Data-parallel: the closing work is two graphs with a collective started behind each, so that the
+            # first bucket (the full-length layer's weights: most of the bytes) is summed over the ranks while
+            # the slab sums of the conv weights run, and its Adam runs while the second bucket is summed.
+            # (On one GPU both halves of the closing work are one graph.)
+            self.graph_early = torch.cuda.CUDAGraph() if bucketed else None
+            self.graph_late = torch.cuda.CUDAGraph()
+            if bucketed:
+                with torch.cuda.graph(self.graph_early):
+                    early = close_early(results)
+                with torch.cuda.graph(self.graph_late):
+                    self.out = close_late(results, early)
+            else:
+                with torch.cuda.graph(self.graph_late):
+                    self.out = close_late(results, close_early(results))
         except BaseException:
             ops.discard_direct_grads()
             raise
-        self.apply = GraphedCall(lambda: self._step(opt, dis, grads=self.bucket)) if bucketed else None
+        self.apply_early = GraphedCall(apply_early) if bucketed and self.bucket_early is not None else None
+        self.apply_late = GraphedCall(apply_late) if bucketed else None
 
-    def _step(self, opt, dis, grads=None):
-        if grads is not None:
-            self.sync.apply(opt, grads)
-        else:
-            opt.step()
+    def _step(self, opt, dis):
+        opt.step()
         ops.refresh_flipped_weights(dis)  # for the next iteration's chains
 
     def __call__(self):
         main = torch.cuda.current_stream()
-        for side, graph in zip(self.sides, self.graphs[1:]):
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+        if self.serial:
+            for graph in self.graphs:
                 graph.replay()
-        self.graphs[0].replay()
-        for side in self.sides:
-            main.wait_stream(side)
-        self.graph_c.replay()
-        if self.bucketed:
-            self.sync.reduce(self.bucket)  # the collective runs between two replays, never inside a capture
-            self.apply()
+        else:
+            for side, graph in zip(self.sides, self.graphs[1:]):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    graph.replay()
+            self.graphs[0].replay()
+            for side in self.sides:
+                main.wait_stream(side)
+        if not self.bucketed:
+            self.graph_late.replay()
+        else:
+            self.graph_early.replay()
+            # collectives are started between replays, never inside a capture
+            sync = self.sync
+            first = sync.reduce(self.bucket_early, async_op=True) if self.bucket_early is not None else None
+            self.graph_late.replay()
+            second = sync.reduce(self.bucket_late, async_op=True) if self.bucket_late is not None else None
+            if self.apply_early is not None:
+                sync.wait(first)
+                self.apply_early()
+            sync.wait(second)
+            self.apply_late()
         ops.bump_weights_epoch()
         return self.out
 

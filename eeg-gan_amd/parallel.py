@@ -73,27 +73,48 @@ class DataParallelStep:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.bucketed = self.world > 1 or always_bucket
-        self.buckets: Dict[int, GradBucket] = {}
+        self.buckets: Dict[tuple, GradBucket] = {}
 
-    def pack(self, module: torch.nn.Module) -> GradBucket:
-        params = [p for p in module.parameters() if p.grad is not None]
-        bucket = self.buckets.get(id(module))
+    def pack(self, module: torch.nn.Module, params=None, slot=None) -> GradBucket:
+        """Gradients of ``module`` (or of the given subset of its parameters) into their persistent bucket.
+        ``slot`` names the bucket when a module's gradients travel in several."""
+        if params is None:
+            params = [p for p in module.parameters() if p.grad is not None]
+        elif any(p.grad is None for p in params):
+            raise RuntimeError("DataParallelStep.pack: a listed parameter has no gradient")
+        key = (id(module), slot)
+        bucket = self.buckets.get(key)
         if bucket is None or bucket.key() != tuple(id(p) for p in params):
             bucket = GradBucket(params)
-            self.buckets[id(module)] = bucket
+            self.buckets[key] = bucket
         bucket.pack()
         return bucket
 
-    def reduce(self, bucket: GradBucket) -> None:
+    def _staged(self, bucket: GradBucket) -> bool:
+        """A host-side backend (rehearsals of the multi-rank path without one GPU per rank): the bucket
+        crosses to host memory and back around the collective."""
+        return bucket.flat.is_cuda and dist.get_backend(self.pg) != "nccl"
+
+    def reduce(self, bucket: GradBucket, async_op: bool = False):
+        """Sum the bucket over the ranks.  With ``async_op`` the collective is only enqueued (behind the work
+        already on the current stream, on the communicator's own stream) and a handle is returned for
+        ``wait``: kernels launched in between run beside it."""
         if not (dist.is_available() and dist.is_initialized()):
-            return
-        if bucket.flat.is_cuda and dist.get_backend(self.pg) != "nccl":
-            # a host-side backend (rehearsals of the multi-rank path without one GPU per rank)
+            return None
+        if self._staged(bucket):
             host = bucket.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
             bucket.flat.copy_(host)
-        else:
-            dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.pg)
+            return None
+        work = dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        return work if async_op else None
+
+    @staticmethod
+    def wait(work) -> None:
+        """Order the current stream behind a collective started with ``reduce(..., async_op=True)`` (the host
+        does not block)."""
+        if work is not None:
+            work.wait()
 
     def apply(self, optimizer, bucket: GradBucket) -> None:
         optimizer.grad_scale = 1.0 / self.world

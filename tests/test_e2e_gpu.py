@@ -535,18 +535,33 @@ def test_full_step_fixture(dev):
             assert e < tol, f"{net}.{k}: update differs by {e:.3e} (tolerance {tol:.3e})"
 
 
-def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0)):
+def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=True, B=8, shard=None, order=None,
+               jitter=0.0):
     """Two training steps at depth 2 with the noise off and fixed mixing factors (so that every
-    variant sees the same random inputs).  Returns the weights, Adam's moments and step counts."""
+    variant sees the same random inputs).  Returns the weights, Adam's moments and step counts.
+    ``parts``: the critic loss can be asked for its independent parts (a graph trainer then runs them as two
+    chains).  ``shard`` = (rank, world): this process takes its share of every batch of ``B`` samples.
+    ``order``: the samples of every batch in another order.  ``jitter``: relative size of a random perturbation
+    of the reals (a few ulps: what another rounding of the same arithmetic does to the inputs)."""
     from eeggan_amd import config
     from eeggan_amd.layers import GDropLayer
     from eeggan_amd.optim import Adam
-    depth, B = 2, 8
+    from eeggan_amd.parallel import shard_batch
+    depth = 2
     T = config.seq_len(depth)
     gen = torch.Generator().manual_seed(4)
-    reals = [torch.randn(B, 5, T, generator=gen).to(dev) for _ in range(10)]
-    zs = [torch.randn(B, 256, generator=gen).to(dev) for _ in range(12)]
-    mix = torch.rand(B, 1, 1, generator=gen).to(dev)
+    if shard is not None:
+        own = lambda t: shard_batch(t, shard[0], shard[1]).contiguous()  # noqa: E731
+    elif order is not None:
+        own = lambda t: t[torch.as_tensor(order)].contiguous()  # noqa: E731
+    else:
+        own = lambda t: t  # noqa: E731
+    reals = [own(torch.randn(B, 5, T, generator=gen)).to(dev) for _ in range(10)]
+    if jitter:
+        jgen = torch.Generator().manual_seed(77)
+        reals = [r * (1 + jitter * torch.randn(r.shape, generator=jgen).to(dev)) for r in reals]
+    zs = [own(torch.randn(B, 256, generator=gen)).to(dev) for _ in range(12)]
+    mix = own(torch.rand(B, 1, 1, generator=gen)).to(dev)
     g, d = config.build_models(9)
     g, d = g.to(dev), d.to(dev)
     g.depth = d.depth = depth
@@ -560,8 +575,11 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0)):
     class _DS:
         model_depth, alpha = depth, 1.0
 
-    tr = cls(d, g, lambda dis, ge, r, z: d_loss_fn(dis, ge, r, z, mixing=mix), g_loss_fn, _DS(),
-             iter([{"z": z} for z in zs]), 0, opt_g, opt_d)
+    if parts:
+        critic_loss = lambda dis, ge, r, z, **kw: d_loss_fn(dis, ge, r, z, mixing=mix, **kw)  # noqa: E731
+    else:
+        critic_loss = lambda dis, ge, r, z: d_loss_fn(dis, ge, r, z, mixing=mix)  # noqa: E731
+    tr = cls(d, g, critic_loss, g_loss_fn, _DS(), iter([{"z": z} for z in zs]), 0, opt_g, opt_d)
     tr.dataiter = iter([{"x": r} for r in reals])
     if sync_factory is not None:
         tr.grad_sync = sync_factory()
@@ -640,10 +658,12 @@ def test_graph_replay_equals_eager(dev):
         base = _two_steps(dev, plain, lr=0.0), _two_steps(dev, plain)
         direct = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
         graphed = _two_steps(dev, GraphedTrainer, lr=0.0), _two_steps(dev, GraphedTrainer)
+        single = _two_steps(dev, GraphedTrainer, lr=0.0, parts=False), _two_steps(dev, GraphedTrainer, parts=False)
     finally:
         layers.set_drop_mode("numpy")
     _same_trajectory(base, direct, "side-stream weight gradients")
-    _same_trajectory(base, graphed, "graph replay")
+    _same_trajectory(base, graphed, "graph replay, critic iteration as two chains")
+    _same_trajectory(base, single, "graph replay, critic iteration as one graph")
 
 
 def test_graph_replay_during_fade_in(dev):
@@ -685,12 +705,107 @@ def test_data_parallel_graphs_equal_eager(dev):
         base = _two_steps(dev, Trainer, lr=0.0), _two_steps(dev, Trainer)
         eager = _two_steps(dev, Trainer, sync, lr=0.0), _two_steps(dev, Trainer, sync)
         graphed = _two_steps(dev, GraphedTrainer, sync, lr=0.0), _two_steps(dev, GraphedTrainer, sync)
+        single = (_two_steps(dev, GraphedTrainer, sync, lr=0.0, parts=False),
+                  _two_steps(dev, GraphedTrainer, sync, parts=False))
     finally:
         layers.set_drop_mode("numpy")
         if own_group:
             dist.destroy_process_group()
     _same_trajectory(base, eager, "eager data-parallel step")
-    _same_trajectory(base, graphed, "graphed data-parallel step")
+    _same_trajectory(base, graphed, "graphed data-parallel step, two chains and two buckets")
+    _same_trajectory(base, single, "graphed data-parallel step, one graph and one bucket")
+
+
+def _two_rank_worker(rank, world, port, out):
+    """One rank of the data-parallel trainer.  Both ranks share the one GPU; the collective is gloo's, on
+    host copies of the buckets (DataParallelStep stages them)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import test_e2e_gpu as T
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.parallel import DataParallelStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    layers.set_drop_mode("device")
+    res = []
+    for lr in (0.0, 0.002):
+        r = T._two_steps(dev, GraphedTrainer, DataParallelStep, lr=lr, B=16, shard=(rank, world))
+        res.append({k: v.cpu().numpy() for k, v in r.items()})
+    if rank == 0:
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_follow_the_global_batch(dev):
+    """Two processes, each with half of every 16-sample batch (whole minibatch-stddev groups, shard_batch),
+    run the graph trainer with DataParallelStep (buckets packed on the device, summed over the ranks, Adam
+    reading the buckets).  Their trajectory must be that of ONE process training on the 16-sample batches: the
+    same weight displacements with lr > 0, and with lr = 0 the same moments up to what another rounding of the
+    same arithmetic does to them.  That is more than an ulp: kernels pick their tiles by batch size, so
+    activations differ in the last bits, a pre-activation within that of zero changes its LeakyReLU branch,
+    and the critic's terms cancel at initialisation, so a gradient is small against its summands (the
+    one-process trainer's own variants differ by 1.7e-3 of a tensor's scale here when the fakes of a step come
+    from one 80-sample generator pass instead of five 16-sample passes, which changes them by 3e-7).  The level
+    is measured, not assumed: the one-process run is repeated with the samples of every batch in another order
+    that keeps the minibatch-stddev groups (their columns rotated) and with the reals perturbed by 1e-6 of
+    their size; the two-rank run may differ from the first by NOISE_FACTOR times the worst tensor's difference
+    among those, and by no more than COND_CAP.  A missing rank, a missing 1/world or a broken shard is an error
+    of 0.5-1."""
+    import torch.multiprocessing as mp
+    import socket
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    rotated = [k * 4 + (c + 1) % 4 for k in range(4) for c in range(4)]
+    layers.set_drop_mode("device")
+    try:
+        base = _two_steps(dev, GraphedTrainer, lr=0.0, B=16), _two_steps(dev, GraphedTrainer, B=16)
+        again = [_two_steps(dev, GraphedTrainer, lr=0.0, B=16, order=rotated),
+                 _two_steps(dev, GraphedTrainer, lr=0.0, B=16, jitter=1e-6)]
+    finally:
+        layers.set_drop_mode("numpy")
+    noise = max(float((a - other[k]).abs().max()) / max(float(a.abs().max()), 1e-30)
+                for other in again for k, a in base[0].items() if k.endswith((".m", ".v")))
+    gate = max(1e-5, min(NOISE_FACTOR * noise, COND_CAP))
+    print(f"rounding noise of the moments (worst tensor): {noise:.2e} -> gate {gate:.2e}")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get() if _wait_for(procs, out, 240) else None
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert res is not None and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    ranks = tuple({k: torch.from_numpy(v).to(dev) for k, v in r.items()} for r in res)
+    worst = max(float((a - ranks[0][k]).abs().max()) / max(float(a.abs().max()), 1e-30)
+                for k, a in base[0].items() if k.endswith((".m", ".v")))
+    print(f"two ranks against the global batch, moments (worst tensor): {worst:.2e}")
+    _same_trajectory(base, ranks, "two ranks against the global batch", moment_tol=gate)
+
+
+def _wait_for(procs, queue, seconds):
+    """True once the queue holds a result; False when a worker has died or the time is up."""
+    import time
+    end = time.time() + seconds
+    while time.time() < end:
+        if not queue.empty():
+            return True
+        if any(p.exitcode not in (None, 0) for p in procs):
+            return False
+        time.sleep(0.2)
+    return False
 
 
 def test_stacked_critic_pass_equals_sequential(dev):
