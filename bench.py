@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--alpha", type=float, default=ALPHA, help="fade-in factor (< 1: mid-transition step)")
     ap.add_argument("--per-iteration-fakes", action="store_true",
                     help="one generator pass per critic iteration instead of one per step (comparison runs)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the conv layers' matrix products: f32 (fp32 products, the headline) or bf16 "
+                         "(operands rounded to bf16, fp32 accumulation and storage: the large-batch mode, looser bounds)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="reals start in pinned host memory and cross PCIe inside the timed region "
                          "(a side measurement; the headline value keeps them resident in HBM)")
@@ -145,7 +148,22 @@ def conv_roofline(dev, batch, T):
     # work against the bf16 pipe it runs on; `bound_frac` prices the algorithmic flops against the tighter
     # of the two ceilings this formulation has: a sixth of the bf16 pipe, and HBM bandwidth x the layer's
     # arithmetic intensity.  EEGGAN_FP32_MFMA=1 selects the fp32 instructions instead.
-    fp32_mfma = os.environ.get("EEGGAN_FP32_MFMA") is not None
+    mode = ops.get_precision()
+    fp32_mfma = mode == "fp32_mfma"
+    if mode == "bf16":
+        # bf16 compute mode: one bf16 MFMA per 16 reduction indices on the operands rounded to bf16; tensors stay
+        # fp32 in memory, so the ceiling is the tighter of the bf16 pipe and HBM bandwidth x arithmetic intensity
+        ceiling = min(BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS * (flops / algorithmic_bytes) / 1e3)
+        hbm_bound = ceiling < BF16_MFMA_PEAK_TFLOPS
+        return {"bound": "hbm" if hbm_bound else "mfma",
+                "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop), bf16 products" % batch,
+                "achieved": round(algorithmic_bytes / per_launch / 1e9, 1) if hbm_bound else round(achieved, 3),
+                "peak": HBM_PEAK_GBS if hbm_bound else BF16_MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(achieved / ceiling, 4), "traffic": None, "avg_launch_us": round(per_launch * 1e6, 2),
+                "back_to_back_us": round(back_to_back * 1e6, 2), "flop_per_launch": flops,
+                "algorithmic_bytes_per_launch": algorithmic_bytes, "tflops": round(achieved, 2),
+                "pipe_frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "matrix_instruction": "1 x v_mfma_f32_32x32x16_bf16 per 16 reduction indices (operands rounded to bf16)"}
     out = {"bound": "mfma", "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop)" % batch,
            "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -291,6 +309,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     from eeggan_amd import layers
     layers.set_drop_mode(args.drop_mode)
+    if args.dtype == "bf16":
+        from eeggan_amd import ops
+        ops.set_precision("bf16")
     tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs)
     if args.per_iteration_fakes:
         tr.batch_fakes = False
@@ -328,7 +349,7 @@ def main():
             "metric": "G+D WGAN-GP train steps/sec (whole node) at final stage",
             "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (reals copied from pinned host memory each iteration)" if args.host_inputs else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (reals copied from pinned host memory each iteration)" if args.host_inputs else ""),
             "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha={args.alpha:g}, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
                        "parallelism": f"dp{world}", "drop_noise": args.drop_mode,
@@ -337,11 +358,12 @@ def main():
         out["roofline"] = conv_roofline(dev, args.batch, T)
         fam = conv_ws_family_flops(lambda: make_trainer(dev, args.depth, args.alpha, args.batch, 1373, 1, 0, eager=True))
         out["roofline"]["in_step"] = in_step_figures(*fam)
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
         out["roofline"]["whole_step"] = {
             "flop_per_step": STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * 1e9 * args.batch,
             "achieved": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3, 2),
             "frac": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3
-                          / FP32_MFMA_PEAK_TFLOPS, 4)}
+                          / peak, 4), "peak": peak}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.depth, args.alpha, args.batch, 1373)
         print(json.dumps(out), flush=True)

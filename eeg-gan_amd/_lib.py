@@ -33,6 +33,8 @@ SIGNATURES = {
     "eeggan_conv1d_pixelnorm": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _fl, _st]),
     "eeggan_conv1d_flip_weights": (_i, [_f, _f, _i, _i, _i, _st]),
     "eeggan_conv1d_flip_weights_multi": (_i, [C.c_void_p, _i, _st]),
+    "eeggan_set_matrix_precision": (_i, [_i]),
+    "eeggan_get_matrix_precision": (_i, []),
     "eeggan_conv1d_wgrad_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "eeggan_conv1d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _f, _fl, _fl, _fl, _f, _sz, _st]),
     "eeggan_conv1d_wgrad_partial": (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _fl, _f, _f, _fl, _f, _sz, C.c_void_p, C.c_void_p,

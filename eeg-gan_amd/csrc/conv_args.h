@@ -55,7 +55,7 @@ constexpr int ACT_LRELU_PN = 4;
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st);
 bool conv_ws_covers(const ConvArgs& a, int K);
 int num_cus();  // compute units of the CURRENT device
-bool split_products();
+int product_pieces();  // pieces per operand of the bf16 matrix products: 3 (fp32 products), 1 (bf16 mode), 0 (fp32 MFMA)
 // One-time launch set-up (LDS opt-in, occupancy) is kept per device in arrays of this many atomics: the
 // entry points are called from autograd's backward thread as well, and a process may drive several GPUs.
 // The set-up calls are idempotent, so two threads racing through one only repeat it.

@@ -19,6 +19,7 @@
 #include "conv_args.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace eeggan {
@@ -162,7 +163,7 @@ struct XStage {
 //   MASK (-1 | 0 | 1): whether the input carries a fused backward mask; -1 decides at run time.  The two-stage
 //   prefetch wants it known at compile time: a branch around the mask loads makes the load counts the waits
 //   are computed from path-dependent, and the waits conservative.
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, bool SPLIT = false, int MASK = -1,
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, int SPLIT = 0, int MASK = -1,
           int NTHR = 64 * WM * WN * KS>
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
@@ -610,6 +611,15 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 const bf16x8s(&w1)[RM][3] = wf[HOISTW ? u : 0];
 #pragma unroll
                 for (int n = 0; n < RN; ++n) {
+                    if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
+                        bf16x8s x1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x1[i] = (__bf16)xr[u][n][i];
+#pragma unroll
+                        for (int i = 0; i < RM; ++i)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][0], acc[i][n], 0, 0, 0);
+                        continue;
+                    }
                     bf16x8s x1, x2, x3;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -783,11 +793,24 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
 
 }  // namespace
 
-// fp32 products from three bf16 pieces on the bf16 matrix pipe (default) or the fp32 matrix instructions
-// (EEGGAN_FP32_MFMA=1 in the environment: comparison runs)
-bool split_products() {
-    static const bool on = getenv("EEGGAN_FP32_MFMA") == nullptr;
-    return on;
+// Matrix products of the predicate-free k = 3 layers: 3 = bf16 matrix instructions on three bf16 pieces per fp32
+// operand (fp32 products; default), 1 = bf16 matrix instructions on the operands rounded to bf16 (bf16 compute
+// mode: fp32 storage and accumulation), 0 = fp32 matrix instructions (comparison runs).  Process-wide; initial
+// value from the environment (EEGGAN_FP32_MFMA=1 -> 0, EEGGAN_PRECISION=bf16 -> 1).
+static int initial_pieces() {
+    if (getenv("EEGGAN_FP32_MFMA") != nullptr) return 0;
+    const char* p = getenv("EEGGAN_PRECISION");
+    return (p != nullptr && strcmp(p, "bf16") == 0) ? 1 : 3;
+}
+static std::atomic<int> g_pieces{-1};
+
+int product_pieces() {
+    int v = g_pieces.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = initial_pieces();
+        g_pieces.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 int current_device() {
@@ -809,7 +832,7 @@ int num_cus() {
 
 namespace {
 
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, bool SPLIT = false, int MASK = -1>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, int SPLIT = 0, int MASK = -1>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
     constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
@@ -864,12 +887,20 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     if constexpr (K == 3) {
         // predicate-free layers: products from bf16 pieces.  The narrow tile is 32 channels x 2 subtiles there (as many
         // tiles as 64 x 1): with the weight chunk as three piece planes that is what still fits twice on a CU.
-        if (full && split_products()) {
+        const int pieces = product_pieces();
+        if (full && pieces == 3) {
             if (a.mask_y)
-                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true, 1>(a, st)
-                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true, 1>(a, st);
-            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, true, 0>(a, st)
-                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, true, 0>(a, st);
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 1>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 1>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 0>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 0>(a, st);
+        }
+        if (full && pieces == 1) {
+            if (a.mask_y)
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 1>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 1>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 0>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 0>(a, st);
         }
     }
     if (big)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)
@@ -949,7 +980,7 @@ unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next w
 // SPLIT (FULL, K = 3): the products run on the bf16 matrix pipe, each fp32 operand as the sum of three bf16
 // pieces with the six leading piece products kept (fp32-exact to 2^-24; see conv_ws.hip): 18 MFMAs of 16
 // time steps replace 24 fp32 MFMAs of 2.
-template <int K, bool FULL, bool SPLIT = false>
+template <int K, bool FULL, int SPLIT = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
     static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
     constexpr int PAD = (K - 1) / 2;
@@ -1001,6 +1032,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                     const float xs[10] = {Xr[n * SUB + tb - 1], x0[0], x0[1], x0[2], x0[3],
                                           x1[0], x1[1], x1[2], x1[3], Xr[n * SUB + tb + 8]};
                     if (do_bias) bsum += ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]));
+                    if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
+                        bf16x8s G1;
+                        __bf16 q1[10];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) G1[i] = (__bf16)(i < 4 ? g0[i] : g1[i - 4]);
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) q1[i] = (__bf16)xs[i];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            bf16x8s X1;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) X1[i] = q1[i + j];
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X1, acc[j], 0, 0, 0);
+                        }
+                        continue;
+                    }
                     bf16x8s G1, G2, G3;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -1208,7 +1255,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     }
 }
 
-template <int K, bool FULL, bool SPLIT = false>
+template <int K, bool FULL, int SPLIT = 0>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_kernel(WgradArgs a) {
     wgrad_body<K, FULL, SPLIT>(a, blockIdx.x, blockIdx.y);
 }
@@ -1224,7 +1271,7 @@ struct WgradPack {
     int n;
 };
 
-template <int K, bool FULL, bool SPLIT = false>
+template <int K, bool FULL, int SPLIT = 0>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
@@ -1310,6 +1357,13 @@ int check_common(int B, int Cin, int Cout, int T, int K) {
 }  // namespace eeggan
 
 using namespace eeggan;
+
+extern "C" int eeggan_set_matrix_precision(int pieces) {
+    EEGGAN_REQUIRE(pieces == 0 || pieces == 1 || pieces == 3, "set_matrix_precision: %d is not one of 0, 1, 3", pieces);
+    eeggan::g_pieces.store(pieces, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int eeggan_get_matrix_precision(void) { return eeggan::product_pieces(); }
 
 extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, const float* drop, float* y, int B,
                              int Cin, int Cout, int T, int K, float in_scale, int act, float act_param,
@@ -1438,13 +1492,19 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true, true>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true, 3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<3, true, 1>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
             EEGGAN_REQUIRE(e == hipSuccess, "%s: cannot reserve LDS: %s", what, hipGetErrorString(e));
             ready.store(true, std::memory_order_release);
         }
-        if (split_products())
-            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, true>), grid, dim3(512), 2 * lds1, st, a);
+        const int pieces = product_pieces();
+        if (pieces == 3)
+            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, 3>), grid, dim3(512), 2 * lds1, st, a);
+        else if (pieces == 1)
+            hipLaunchKernelGGL((conv_wgrad_kernel<3, true, 1>), grid, dim3(512), 2 * lds1, st, a);
         else
             hipLaunchKernelGGL((conv_wgrad_kernel<3, true>), grid, dim3(256), 2 * lds1, st, a);
     } else if (K == 3) {
@@ -1684,14 +1744,20 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     if (e == hipSuccess)
-                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, true>),
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, 3>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                    if (e == hipSuccess)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad_partial_multi: cannot reserve LDS: %s",
                                    hipGetErrorString(e));
                     ready.store(true, std::memory_order_release);
                 }
-                if (split_products())
-                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, true>), dim3(first), dim3(512), 2 * lds1, st, pk);
+                const int pieces = product_pieces();
+                if (pieces == 3)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3>), dim3(first), dim3(512), 2 * lds1, st, pk);
+                else if (pieces == 1)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
             } else if (v == 1) {

@@ -60,9 +60,13 @@ __device__ __forceinline__ void split3(float v, __bf16& p1, __bf16& p2, __bf16& 
 // RM = 1: a unit is one half of the output channels of a subtile (units 2s and 2s+1 share subtile s
 // and are taken by neighbouring waves): twice the input reads, but twice as many, half as long units,
 // which balances the four SIMDs of a CU when a layer has only a few subtiles per CU.
-template <int K, bool MASKED, bool FULL, int RM, bool SPLIT = false>
+// SPLIT: 0 = fp32 matrix instructions; 3 = bf16 matrix instructions on three pieces per operand (fp32 products);
+// 1 = bf16 matrix instructions on the operands rounded to bf16 (the bf16 compute mode: one product instead of six,
+// no splitting; fp32 accumulation, fp32 in and out).
+template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3), "the split form covers the 64 -> 64, k = 3 layers");
+    static_assert(SPLIT == 0 || SPLIT == 1 || SPLIT == 3, "pieces per operand");
     constexpr int PAD = (K - 1) / 2;
     constexpr int KK = 64 * K;   // reduction length with the input channels padded to 64
     constexpr int WLD = KK + 4;  // (WLD / 4) odd: conflict-free 16-byte row reads
@@ -298,6 +302,18 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 const char* Wb = reinterpret_cast<const char*>(smem) + (co_base + l31) * WROWB + (h * 4 + c) * 3 * 16;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
+                    if constexpr (SPLIT == 1) {
+                        bf16x8 x1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x1[i] = (__bf16)Bp[(8 * c + i) * XL + j];
+#pragma unroll
+                        for (int tile = 0; tile < RM; ++tile) {
+                            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(Wb + tile * 32 * WROWB + j * 16);
+                            f32x16& acc = tile == 0 ? acc0 : acc1;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1, acc, 0, 0, 0);
+                        }
+                        continue;
+                    }
                     bf16x8 x1, x2, x3;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     unit_body(std::false_type{}, cur);
 }
 
-template <int K, bool MASKED, bool FULL, int RM, bool SPLIT = false>
+template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0>
 int launch(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)((SPLIT ? 3 * WPLANE / 4 : 64 * (64 * K + 4)) + WS_WAVES * XREG) * sizeof(float);
     auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM, SPLIT>;
@@ -490,13 +506,16 @@ int launch_rm(const ConvArgs& a, hipStream_t st) {
     const long long whole = (a.NS + waves - 1) / waves * 2, half = (2ll * a.NS + waves - 1) / waves;
     const bool halves = a.act != ACT_LRELU_PN && (a.NS < waves || half < whole);  // (the norm needs all channels in one unit)
     if constexpr (FULL && K == 3) {
-        // (EEGGAN_FP32_MFMA=1 in the environment keeps the fp32 matrix instructions: comparison runs)
-        if (split_products()) {
+        // (product_pieces() == 0 keeps the fp32 matrix instructions: comparison runs)
+        const int pieces = product_pieces();
+        if (pieces) {
             // With the split products a unit's cost is mostly the splitting of its input, which a whole unit does
             // once for both halves of the output channels: a whole unit counts 1.3 half units, not 2 (i.e. half
             // units only while they fit one round of the chip's waves; measured +1.2 % steps/s, 1.6 the same).
             const bool halves_s = a.act != ACT_LRELU_PN && half * 10 < (whole / 2) * 13;
-            return halves_s ? launch<K, MASKED, FULL, 1, true>(a, st) : launch<K, MASKED, FULL, 2, true>(a, st);
+            if (pieces == 1)
+                return halves_s ? launch<K, MASKED, FULL, 1, 1>(a, st) : launch<K, MASKED, FULL, 2, 1>(a, st);
+            return halves_s ? launch<K, MASKED, FULL, 1, 3>(a, st) : launch<K, MASKED, FULL, 2, 3>(a, st);
         }
     }
     return halves ? launch<K, MASKED, FULL, 1>(a, st) : launch<K, MASKED, FULL, 2>(a, st);

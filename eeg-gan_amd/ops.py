@@ -138,6 +138,26 @@ class FlipCache:
         return self.wt
 
 
+_PRECISIONS = {"fp32": 3, "bf16": 1, "fp32_mfma": 0}
+
+
+def set_precision(mode: str) -> str:
+    """Arithmetic of the conv layers' matrix products for the launches that follow (process-wide; captured graphs
+    keep the mode they were captured in): 'fp32' (default: fp32 products from three bf16 pieces per operand),
+    'bf16' (operands rounded to bf16, fp32 accumulation and storage: the large-batch mode, with its looser
+    bounds) or 'fp32_mfma' (fp32 matrix instructions; comparison runs).  Returns the previous mode."""
+    if mode not in _PRECISIONS:
+        raise ValueError(f"precision {mode!r}: expected one of {sorted(_PRECISIONS)}")
+    previous = get_precision()
+    call("eeggan_set_matrix_precision", _PRECISIONS[mode])
+    return previous
+
+
+def get_precision() -> str:
+    pieces = _lib.load().eeggan_get_matrix_precision()
+    return next(k for k, v in _PRECISIONS.items() if v == pieces)
+
+
 def refresh_flipped_weights(module):
     """Rebuild, on the current stream, every stale flipped view of ``module`` that an input gradient has asked
     for before (one launch).  For callers that run passes over the module on several streams: the views are

@@ -71,6 +71,16 @@ typedef struct {
     const float* w; float* wt; int Cout, Cin, K, reserved;
 } eeggan_flip_desc;
 int eeggan_conv1d_flip_weights_multi(const eeggan_flip_desc* table, int ntensors, void* stream);
+/* Arithmetic of the matrix products of the predicate-free k = 3 conv layers (forward, input gradient and weight
+ * gradient; they carry nearly all of the step's flops), process-wide, for the launches that follow:
+ *   3  bf16 matrix instructions on three bf16 pieces per fp32 operand: fp32 products (default; the reference is
+ *      fp32 throughout, layers.py:150-174)
+ *   1  bf16 compute mode: operands rounded to bf16, one product; fp32 accumulation, fp32 tensors in memory
+ *   0  fp32 matrix instructions (comparison runs)
+ * Returns non-zero for any other value.  The ragged layers (5 or 257 channels), the k = 1 and the full-length
+ * layers use fp32 matrix instructions in every mode. */
+int eeggan_set_matrix_precision(int pieces);
+int eeggan_get_matrix_precision(void);
 
 /* Weight- and bias-gradient of the same convolution (autograd of nn.Conv1d, layers.py:154-155):
  *   gw[co,ci,j] = in_scale * sum_{b,t} gy[b,co,t] * x[b,ci,t+j-pad],  gb[co] = sum_{b,t} gy[b,co,t]
