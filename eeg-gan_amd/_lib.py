@@ -83,6 +83,11 @@ SIGNATURES = {
     "eeggan_feature_stats": (_i, [_f, _sz, _i, _f, _f, C.c_void_p, _sz, _st]),
     "eeggan_adam_step": (_i, [C.c_void_p, _i, _fl, _fl, _fl, _fl, _fl, _st]),
     "eeggan_multi_copy": (_i, [C.c_void_p, _i, _st]),
+    "eeggan_multi_axpby": (_i, [C.c_void_p, _i, _fl, _fl, _st]),
+    "eeggan_score_loss": (_i, [_i, _f, _f, _i, _fl, _f, _f, _f, _st]),
+    "eeggan_scale_by_scalar": (_i, [_f, _f, _f, _sz, _st]),
+    "eeggan_grad_penalty_fwd": (_i, [_f, _f, _f, _i, _sz, _fl, _fl, _i, _st]),
+    "eeggan_grad_penalty_bwd": (_i, [_f, _f, _f, _f, _i, _sz, _fl, _fl, _i, _st]),
 }
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_MASK = 0, 1, 2, 3

@@ -51,10 +51,13 @@ def build_models(seed: int = RANDOM_SEED, generator_cls=None, discriminator_cls=
     return g, d
 
 
-def loss_closures():
+def loss_closures(**overrides):
+    """(critic loss, generator loss) bound to the reference's default loss settings (defaults.yml), or to
+    ``overrides`` of them (``loss_type``, ``grad_lambda``, ...)."""
     from .losses import discriminator_loss, generator_loss
-    d_loss = partial(discriminator_loss, **LOSS)
-    g_loss = partial(generator_loss, random_multiply=False, loss_type=LOSS["loss_type"], feature_matching_lambda=0.0)
+    settings = {**LOSS, **overrides}
+    d_loss = partial(discriminator_loss, **settings)
+    g_loss = partial(generator_loss, random_multiply=False, loss_type=settings["loss_type"], feature_matching_lambda=0.0)
     return d_loss, g_loss
 
 

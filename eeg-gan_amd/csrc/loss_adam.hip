@@ -68,6 +68,119 @@ __global__ __launch_bounds__(256) void mean_scale_bwd_kernel(const float* __rest
     if (i < n) out[i] = gl[0] * scale / (float)n;
 }
 
+// ---- the other score losses of the reference (losses.py:47-60, 82-101) ----------------------------------------
+// One workgroup: value of the loss term and its gradient w.r.t. both score vectors (for an upstream gradient of
+// one), from two score vectors a, b of length B.  As the critic's loss a = D(real), b = D(fake); the generator's
+// relativistic losses are the same functions with the roles swapped (a = D(fake), b = D(real)).
+//   1 hinge            mean relu(1 - a) + mean relu(1 + b)
+//   2 rsgan            mean softplus(-(a - b))                                   (= BCE-with-logits(a - b, 1))
+//   3 rasgan           (mean softplus(-(a - mean b)) + mean softplus(b - mean a)) / 2
+//   4 rahinge          (mean relu(1 - (a - mean b)) + mean relu(1 + (b - mean a))) / 2
+//   5 wgan_theirs      mean b - mean a + eps (mean a + mean b)^2                 (score part; its penalty is scaled by 6)
+//   6 gain             relu(mean a - mean b)
+__device__ __forceinline__ float softplus_f(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void score_loss_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b,
+                                                         int B, float eps, float* __restrict__ loss,
+                                                         float* __restrict__ ga, float* __restrict__ gb) {
+    __shared__ float red[4];
+    const float invB = 1.f / (float)B;
+    float sa = 0.f, sb = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        sa += a[i];
+        sb += b[i];
+    }
+    const float ma = block_sum_256(sa, red) * invB;
+    const float mb = block_sum_256(sb, red) * invB;
+    if (kind == 5 || kind == 6) {
+        const float val = kind == 5 ? mb - ma + eps * (ma + mb) * (ma + mb) : fmaxf(ma - mb, 0.f);
+        const float da = kind == 5 ? -1.f + 2.f * eps * (ma + mb) : (ma > mb ? 1.f : 0.f);
+        const float db = kind == 5 ? 1.f + 2.f * eps * (ma + mb) : (ma > mb ? -1.f : 0.f);
+        for (int i = threadIdx.x; i < B; i += 256) {
+            ga[i] = da * invB;
+            gb[i] = db * invB;
+        }
+        if (threadIdx.x == 0) loss[0] = val;
+        return;
+    }
+    // per-element terms u_i (depends on a_i) and v_i (depends on b_i), their derivatives du_i, dv_i w.r.t. their
+    // arguments, and for the relativistic-average forms the means of those derivatives
+    const bool avg = kind == 3 || kind == 4;
+    float sl = 0.f, sdu = 0.f, sdv = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const float x = a[i], y = b[i];
+        float u, v, du, dv;
+        if (kind == 1) {
+            u = fmaxf(1.f - x, 0.f), du = x < 1.f ? -1.f : 0.f;
+            v = fmaxf(1.f + y, 0.f), dv = y > -1.f ? 1.f : 0.f;
+        } else if (kind == 2) {
+            u = softplus_f(-(x - y)), du = -sigmoid_f(-(x - y));
+            v = 0.f, dv = -du;
+        } else if (kind == 3) {
+            u = 0.5f * softplus_f(-(x - mb)), du = -0.5f * sigmoid_f(-(x - mb));
+            v = 0.5f * softplus_f(y - ma), dv = 0.5f * sigmoid_f(y - ma);
+        } else {
+            u = 0.5f * fmaxf(1.f - (x - mb), 0.f), du = 1.f - (x - mb) > 0.f ? -0.5f : 0.f;
+            v = 0.5f * fmaxf(1.f + (y - ma), 0.f), dv = 1.f + (y - ma) > 0.f ? 0.5f : 0.f;
+        }
+        sl += u + v;
+        sdu += du;
+        sdv += dv;
+        ga[i] = du;
+        gb[i] = dv;
+    }
+    const float tot = block_sum_256(sl, red);
+    const float mdu = block_sum_256(sdu, red) * invB;
+    const float mdv = block_sum_256(sdv, red) * invB;
+    // d/da_i = (du_i - mean dv) / B, d/db_i = (dv_i - mean du) / B for the average forms (the means enter every
+    // element of the other vector with a minus sign); plain per-element derivatives over B otherwise
+    for (int i = threadIdx.x; i < B; i += 256) {
+        ga[i] = (ga[i] - (avg ? mdv : 0.f)) * invB;
+        gb[i] = (gb[i] - (avg ? mdu : 0.f)) * invB;
+    }
+    if (threadIdx.x == 0) loss[0] = tot * invB;
+}
+
+// out = s[0] * v  (a loss gradient scaled by the upstream gradient, a device scalar)
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ s, const float* __restrict__ v,
+                                                              float* __restrict__ out, size_t n) {
+    const float k = s[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = k * v[i];
+}
+
+// Gradient penalty alone: lambda / target^2 * mean(p_b^2), p_b = |g_b| - target, or its one-sided form
+// p_b = relu(|g_b| - target) (losses.py:113-118).  norms[b] = |g_b| is kept for the backward kernel.
+__global__ __launch_bounds__(256) void grad_penalty_final_kernel(const float* __restrict__ norms, float* __restrict__ loss,
+                                                                 int B, float lambda, float target, int one_sided) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        float p = norms[b] - target;
+        if (one_sided) p = fmaxf(p, 0.f);
+        s += p * p;
+    }
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss[0] = lambda / (target * target) * tot / (float)B;
+}
+
+__global__ __launch_bounds__(256) void grad_penalty_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ g,
+                                                               const float* __restrict__ norms, float* __restrict__ g_g,
+                                                               int B, size_t per, float lambda, float target,
+                                                               int one_sided) {
+    const float up = gl[0];
+    const float invB = 1.f / (float)B;
+    const size_t n = (size_t)B * per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / per;
+        const float nb = norms[b];
+        float p = nb - target;
+        if (one_sided) p = fmaxf(p, 0.f);
+        const float k = nb > 0.f ? up * lambda / (target * target) * 2.f * p * invB / nb : 0.f;
+        g_g[i] = k * g[i];
+    }
+}
+
 // ---- multi-tensor kernels ---------------------------------------------------------------------
 // The descriptor table travels BY VALUE in the kernel arguments (<= 64 tensors, 3 KiB): no device
 // table, no host->device copy, and a captured launch keeps its pointers.  A workgroup owns one
@@ -157,6 +270,18 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(Pack pk) {
     for (int64_t i = start + threadIdx.x; i < end; i += 256) t.p[i] = t.g[i];
 }
 
+// p = alpha * p + beta * g over a table of tensor pairs (the running average of the generator's weights,
+// plugins.py:305-307: alpha = old_weight, beta = 1 - old_weight)
+__global__ __launch_bounds__(256) void multi_axpby_kernel(Pack pk, float alpha, float beta) {
+    int ti;
+    int64_t start;
+    if (!locate(pk, blockIdx.x, &ti, &start)) return;
+    const eeggan_adam_tensor t = pk.t[ti];
+    int64_t end = start + CHUNK;
+    if (end > t.n) end = t.n;
+    for (int64_t i = start + threadIdx.x; i < end; i += 256) t.p[i] = alpha * t.p[i] + beta * t.g[i];
+}
+
 int make_pack(const char* what, const eeggan_adam_tensor* table, int first, int ntensors, Pack* pk, int64_t* blocks) {
     pk->n = ntensors - first < MAXT ? ntensors - first : MAXT;
     *blocks = 0;
@@ -227,6 +352,57 @@ extern "C" int eeggan_adam_step(const eeggan_adam_tensor* table, int ntensors, f
         if (check_launch("adam_step")) return 1;
         hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(MAXT), 0, as_stream(stream), pk);
         if (check_launch("adam_step tick")) return 1;
+    }
+    return 0;
+}
+
+extern "C" int eeggan_score_loss(int kind, const float* a, const float* b, int B, float eps, float* loss, float* ga,
+                                 float* gb, void* stream) {
+    EEGGAN_REQUIRE(a && b && loss && ga && gb, "score_loss: null pointer");
+    EEGGAN_REQUIRE(kind >= 1 && kind <= 6, "score_loss: kind %d outside 1..6", kind);
+    EEGGAN_REQUIRE(B > 0, "score_loss: empty batch");
+    hipLaunchKernelGGL(score_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), kind, a, b, B, eps, loss, ga, gb);
+    return check_launch("score_loss");
+}
+
+extern "C" int eeggan_scale_by_scalar(const float* s, const float* v, float* out, size_t n, void* stream) {
+    EEGGAN_REQUIRE(s && v && out && n > 0, "scale_by_scalar: bad argument");
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), s, v, out, n);
+    return check_launch("scale_by_scalar");
+}
+
+extern "C" int eeggan_grad_penalty_fwd(const float* g, float* norms, float* loss, int B, size_t per, float lambda,
+                                       float target, int one_sided, void* stream) {
+    EEGGAN_REQUIRE(g && norms && loss, "grad_penalty_fwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && per > 0 && target != 0.f, "grad_penalty_fwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(256), 0, st, g, norms, per);
+    if (check_launch("grad_penalty_fwd norms")) return 1;
+    hipLaunchKernelGGL(grad_penalty_final_kernel, dim3(1), dim3(256), 0, st, norms, loss, B, lambda, target, one_sided);
+    return check_launch("grad_penalty_fwd");
+}
+
+extern "C" int eeggan_grad_penalty_bwd(const float* gl, const float* g, const float* norms, float* g_g, int B,
+                                       size_t per, float lambda, float target, int one_sided, void* stream) {
+    EEGGAN_REQUIRE(gl && g && norms && g_g, "grad_penalty_bwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && per > 0 && target != 0.f, "grad_penalty_bwd: bad argument");
+    size_t nb = ((size_t)B * per + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(grad_penalty_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), gl, g, norms, g_g,
+                       B, per, lambda, target, one_sided);
+    return check_launch("grad_penalty_bwd");
+}
+
+extern "C" int eeggan_multi_axpby(const eeggan_adam_tensor* table, int ntensors, float alpha, float beta, void* stream) {
+    EEGGAN_REQUIRE(table && ntensors > 0, "multi_axpby: bad table");
+    for (int first = 0; first < ntensors; first += MAXT) {
+        Pack pk;
+        int64_t nb;
+        if (make_pack("multi_axpby", table, first, ntensors, &pk, &nb)) return 1;
+        hipLaunchKernelGGL(multi_axpby_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), pk, alpha, beta);
+        if (check_launch("multi_axpby")) return 1;
     }
     return 0;
 }

@@ -321,9 +321,14 @@ class GraphedTrainer(Trainer):
             bucket = box["bucket"]
             return first, bucket, GraphedCall(lambda: sync.apply(optimizer, bucket))
 
+        self._d_parts = None
         if self.split_critic and self._fake is not None and _accepts(self.d_loss, "part"):
-            self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed, parts=self.critic_chains)
-        else:
+            from .losses import PartsUnavailable
+            try:
+                self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed, parts=self.critic_chains)
+            except PartsUnavailable:  # a loss whose terms do not separate: one graph per iteration
+                _restore(snap)
+        if self._d_parts is None:
             self._d_parts = iteration(d_loss_fn, self.discriminator, self.optimizer_d)
         self._g_parts = iteration(self.g_loss, self.generator, self.optimizer_g)
         _restore(snap)

@@ -66,13 +66,22 @@ def _frozen(module: torch.nn.Module):
             p.requires_grad_(True)
 
 
+LOSS_TYPES = ("hinge", "rsgan", "rasgan", "rahinge", "wgan_gp", "wgan_theirs")
+
+
+class PartsUnavailable(ValueError):
+    """The critic loss was asked for one of its independent parts but does not split for this configuration."""
+
+
 def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str, random_multiply: bool,
                    feature_matching_lambda: float = 0.0, skip_dis_weight_grads: bool = True):
-    """-mean(D(G(z))).  ``skip_dis_weight_grads`` (default on) leaves ``dis`` parameters' ``.grad``
+    """-mean(D(G(z))) for ``hinge`` and the ``wgan`` family; the relativistic losses (``rsgan``, ``rasgan``,
+    ``rahinge``) compare with the critic's scores of the reals, evaluated without a graph after the fakes' pass
+    (reference losses.py:40-60).  ``skip_dis_weight_grads`` (default on) leaves ``dis`` parameters' ``.grad``
     untouched: the reference accumulates them here only to zero them at the next discriminator
     step (losses.py:75), so they are never used."""
-    if not (loss_type == "hinge" or loss_type.startswith("wgan")):
-        raise NotImplementedError(f"loss_type={loss_type!r}: only the wgan family is supported")
+    if loss_type not in LOSS_TYPES and not loss_type.startswith("wgan"):
+        raise ValueError("Invalid loss type")
     if random_multiply or feature_matching_lambda != 0.0:
         raise NotImplementedError("random_multiply / feature matching are not supported")
     layers.drop_pool_reset()
@@ -80,7 +89,12 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
     g_, _ = gen(z)
     with (_frozen(dis) if skip_dis_weight_grads else contextlib.nullcontext()):
         d_fake, _, _ = dis(g_)
-    return ops.mean_scale(d_fake, -1.0)
+    if loss_type == "hinge" or loss_type.startswith("wgan"):
+        return ops.mean_scale(d_fake, -1.0)
+    with torch.no_grad():
+        d_real, _, _ = dis(real)
+    # the generator's relativistic losses are the critic's with the roles of the two score vectors swapped
+    return ops.score_loss(loss_type, d_fake.reshape(-1), d_real.reshape(-1))
 
 
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,
@@ -97,12 +111,15 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
     only): return only -mean D(real) + mean D(fake) + drift term, or only the gradient penalty; their sum is
     the loss ('real' and 'fake' split the score term once more, into a critic pass each).  ``zero_grad=False`` leaves the critic's gradients alone (the second part of a split
     iteration)."""
-    if loss_type != "wgan_gp":
-        raise NotImplementedError(f"loss_type={loss_type!r}: only 'wgan_gp' is supported")
-    if grad_lambda == 0:
-        raise NotImplementedError("grad_lambda == 0 (no penalty) is not supported")
+    if loss_type not in LOSS_TYPES:
+        raise ValueError("Invalid loss type")
     if part not in (None, "scores", "penalty", "real", "fake"):
         raise ValueError(f"part={part!r}")
+    if loss_type != "wgan_gp":
+        return _other_discriminator_loss(dis, gen, real, z, loss_type, iwass_drift_epsilon, grad_lambda, iwass_target,
+                                         mixing, stack_real_fake, fake, part, zero_grad)
+    if grad_lambda == 0:
+        raise NotImplementedError("wgan_gp with grad_lambda == 0 (no penalty) is not supported")
     layers.drop_pool_reset()
     if zero_grad:
         dis.zero_grad()
@@ -160,3 +177,66 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
     pred_hat, _, _ = dis(x_hat)
     g = calc_grad(x_hat["x"], pred_hat).view(real_x.size(0), -1)
     return ops.wgan_gp_d_loss(d_real, d_fake, g, iwass_drift_epsilon, grad_lambda, iwass_target)
+
+
+def _other_discriminator_loss(dis, gen, real, z, loss_type, drift, grad_lambda, target, mixing, stack_real_fake, fake,
+                              part, zero_grad):
+    """The reference's other critic losses (losses.py:82-101): a term of the two score vectors, plus the gradient
+    penalty on the interpolates when ``grad_lambda`` is not zero (two-sided like wgan_gp's; ``wgan_theirs`` takes
+    the one-sided form and scales it by relu(mean D(real) - mean D(fake)), losses.py:96-98, 115-117).  Pass
+    structure, stacking and ``part`` as in ``discriminator_loss``; ``wgan_theirs`` does not split (its penalty
+    is scaled by a function of the scores) and neither does a loss without penalty."""
+    if part in ("real", "fake") or (part is not None and (loss_type == "wgan_theirs" or grad_lambda == 0)):
+        raise PartsUnavailable(f"loss_type={loss_type!r}, grad_lambda={grad_lambda}: part={part!r} is not available")
+    layers.drop_pool_reset()
+    if zero_grad:
+        dis.zero_grad()
+    real_x = real["x"] if isinstance(real, dict) else real
+    n = real_x.size(0)
+    if stack_real_fake is None:
+        stack_real_fake = layers.get_drop_mode() == "device"
+    if part is not None and not stack_real_fake:
+        raise ValueError("part needs the stacked critic pass")
+    d_real = d_fake = None
+    if stack_real_fake:
+        if fake is None:
+            with torch.no_grad():
+                fake_x = gen(z)[0]["x"]
+        else:
+            fake_x = fake
+        if part != "penalty":
+            with layers.batch_segments(2):
+                scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+            scores = scores.reshape(-1)
+            d_real, d_fake = scores[:n], scores[n:]
+    else:  # the reference's order of passes (and of noise draws): D(real), G(z), D(fake), D(x_hat)
+        d_real = dis(real)[0].reshape(-1)
+        if fake is None:
+            with torch.no_grad():
+                fake_x = gen(z)[0]["x"]
+        else:
+            fake_x = fake
+        d_fake = dis({"x": fake_x})[0].reshape(-1)
+    loss = gain = None
+    if part != "penalty":
+        if loss_type == "wgan_theirs":
+            loss = ops.score_loss("wgan_theirs", d_real, d_fake, drift)
+            gain = ops.score_loss("gain", d_real, d_fake)
+        else:
+            loss = ops.score_loss(loss_type, d_real, d_fake)
+        if part == "scores":
+            return loss
+    if grad_lambda == 0:
+        return loss
+    if gain is not None and layers.get_drop_mode() != "device" and float(gain) == 0.0:
+        # the reference skips the interpolates' pass when the gain is zero (losses.py:103), and with it that
+        # pass's noise draws from the host generator: follow it where the draws follow the reference's stream
+        return loss
+    alpha = get_mixing_factor(n) if mixing is None else mixing
+    x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
+    pred_hat, _, _ = dis(x_hat)
+    g = calc_grad(x_hat["x"], pred_hat).view(n, -1)
+    penalty = ops.grad_penalty(g, grad_lambda, target, one_sided=(loss_type == "wgan_theirs"))
+    if part == "penalty":
+        return penalty
+    return loss + (penalty if gain is None else gain * penalty)

@@ -1110,6 +1110,98 @@ class _WganGpLossStacked(Function):
         return g_s, g_g, None, None, None
 
 
+SCORE_LOSS_KINDS = {"hinge": 1, "rsgan": 2, "rasgan": 3, "rahinge": 4, "wgan_theirs": 5, "gain": 6}
+
+
+class _ScoreLoss(Function):
+    """A loss term of two score vectors (``eeggan_score_loss``): value and both gradients come from one launch,
+    the backward only scales the stored gradients by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, eps):
+        a, b = _chk(a, "scores a"), _chk(b, "scores b")
+        if a.numel() != b.numel():
+            raise RuntimeError(f"score loss: {a.numel()} and {b.numel()} scores")
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        call("eeggan_score_loss", kind, a.data_ptr(), b.data_ptr(), a.numel(), eps, loss.data_ptr(), ga.data_ptr(),
+             gb.data_ptr(), _stream())
+        ctx.save_for_backward(ga, gb)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        ga, gb = ctx.saved_tensors
+        gl = _chk(gl, "loss grad")
+        out = []
+        for need, g in zip(ctx.needs_input_grad[:2], (ga, gb)):
+            if not need:
+                out.append(None)
+                continue
+            o = torch.empty_like(g)
+            call("eeggan_scale_by_scalar", gl.data_ptr(), g.data_ptr(), o.data_ptr(), g.numel(), _stream())
+            out.append(o)
+        return out[0], out[1], None, None
+
+
+def score_loss(kind: str, a, b, eps: float = 0.0):
+    """The reference's non-default loss terms on two score vectors (see ``eeggan_score_loss``): critic losses with
+    a = D(real), b = D(fake); the generator's relativistic losses with a = D(fake), b = D(real)."""
+    if kind not in SCORE_LOSS_KINDS:
+        raise ValueError(f"score loss {kind!r}: expected one of {sorted(SCORE_LOSS_KINDS)}")
+    return _ScoreLoss.apply(a, b, SCORE_LOSS_KINDS[kind], float(eps))
+
+
+class _GradPenalty(Function):
+    @staticmethod
+    def forward(ctx, g, lam, target, one_sided):
+        g = _chk(g, "penalty gradient")
+        B = g.shape[0]
+        per = g.numel() // B
+        norms = torch.empty((B,), device=g.device, dtype=torch.float32)
+        loss = torch.empty((), device=g.device, dtype=torch.float32)
+        call("eeggan_grad_penalty_fwd", g.data_ptr(), norms.data_ptr(), loss.data_ptr(), B, per, lam, target,
+             int(one_sided), _stream())
+        ctx.save_for_backward(g, norms)
+        ctx.cfg = (lam, target, int(one_sided))
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        g, norms = ctx.saved_tensors
+        lam, target, one_sided = ctx.cfg
+        gl = _chk(gl, "loss grad")
+        B = g.shape[0]
+        g_g = torch.empty_like(g)
+        call("eeggan_grad_penalty_bwd", gl.data_ptr(), g.data_ptr(), norms.data_ptr(), g_g.data_ptr(), B,
+             g.numel() // B, lam, target, one_sided, _stream())
+        return g_g, None, None, None
+
+
+def grad_penalty(g, lam, target, one_sided=False):
+    """lam / target^2 * mean((|g_b| - target)^2) over the rows of g [B, per]; ``one_sided``: relu(|g_b| - target)."""
+    return _GradPenalty.apply(g, float(lam), float(target), bool(one_sided))
+
+
+def ema_update(averages, params, old_weight: float):
+    """averages[k] = old_weight * averages[k] + (1 - old_weight) * params[k] for two lists of tensors, in one launch
+    per 64 tensors (the running average of the generator's weights, reference plugins.py:305-307)."""
+    from . import optim
+    rows = []
+    for avg, p in zip(averages, params):
+        if not avg.is_contiguous():
+            raise RuntimeError("ema_update: the averages are updated in place and must be contiguous")
+        avg, p = _chk(avg, "ema average"), _chk(p.detach(), "ema parameter")
+        if avg.numel() != p.numel():
+            raise RuntimeError("ema_update: an average and its parameter differ in size")
+        rows.append((avg.data_ptr(), p.data_ptr(), 0, 0, 0, avg.numel()))
+    if rows:
+        call("eeggan_multi_axpby", optim.build_table(rows), len(rows), float(old_weight), 1.0 - float(old_weight),
+             _stream())
+
+
 def wgan_gp_d_loss_stacked(scores, g, drift, lam, target):
     """``wgan_gp_d_loss(scores[:B], scores[B:], ...)`` without slicing the scores."""
     return _WganGpLossStacked.apply(scores, g, float(drift), float(lam), float(target))

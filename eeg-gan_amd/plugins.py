@@ -108,6 +108,67 @@ class DepthManager(Plugin):
         tr.stats["alpha"]["val"] = alpha
 
 
+class OutputGenerator(Plugin):
+    """The running average of the generator's weights and samples drawn from it (reference plugins.py:235-315):
+    every epoch tick ``avg = old_weight * avg + (1 - old_weight) * weight`` for all parameters (one multi-tensor
+    launch), and every ``output_snapshot_ticks`` ticks a batch of samples generated with the averaged weights
+    swapped in.  The reference then plots those samples and writes PNG files and a checkpoint (matplotlib,
+    imageio, plugins.py:271-315); this class stops at the samples (``self.last_samples``, a device tensor)
+    and, when ``checkpoints_dir`` is given, the ``smooth_generator`` checkpoint."""
+
+    def __init__(self, sample_fn, checkpoints_dir, seq_len: int, max_freq: float, samples_count: int = 8,
+                 output_snapshot_ticks: int = 25, old_weight: float = 0.59):
+        super().__init__([(1, "epoch")])
+        self.old_weight = old_weight
+        self.sample_fn = sample_fn
+        self.samples_count = samples_count
+        self.checkpoints_dir = checkpoints_dir
+        self.seq_len = seq_len
+        self.max_freq = max_freq
+        self.my_g_clone = None
+        self.output_snapshot_ticks = output_snapshot_ticks
+        self.last_samples = None
+
+    @staticmethod
+    def flatten_params(model):
+        return [p.detach().clone() for p in model.parameters()]
+
+    @staticmethod
+    def load_params(flattened, model):
+        import torch
+        from . import ops
+        with torch.no_grad():
+            for p, avg_p in zip(model.parameters(), flattened):
+                p.copy_(avg_p)
+        ops.bump_weights_epoch()  # derived weight views are stale
+
+    def register(self, trainer):
+        self.trainer = trainer
+        self.my_g_clone = self.flatten_params(self.trainer.generator)
+
+    def epoch(self, epoch_index):
+        import os
+        import torch
+        from . import ops
+        from .utils import cudize
+        gen = self.trainer.generator
+        ops.ema_update(self.my_g_clone, list(gen.parameters()), self.old_weight)
+        if epoch_index % self.output_snapshot_ticks != 0:
+            return
+        z = cudize(next(self.sample_fn(self.samples_count)))
+        original = self.flatten_params(gen)
+        self.load_params(self.my_g_clone, gen)
+        try:
+            if self.checkpoints_dir:
+                dest = os.path.join(self.checkpoints_dir, "network-snapshot-smooth_generator-{:06}.dat".format(
+                    self.trainer.cur_nimg // 1000))
+                torch.save({"cur_nimg": self.trainer.cur_nimg, "model": gen.state_dict()}, dest)
+            with torch.no_grad():
+                self.last_samples = gen(z)[0]["x"]
+        finally:
+            self.load_params(original, gen)
+
+
 def __getattr__(name):
     # the metric plugins keep the reference's import path (plugins.SlicedWDistance, plugins.FidCalculator) but
     # live in metrics.py, which imports this module for the Plugin base class

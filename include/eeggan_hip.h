@@ -236,6 +236,27 @@ int eeggan_wgan_gp_loss_fwd(const float* d_real, const float* d_fake, const floa
 int eeggan_wgan_gp_loss_bwd(const float* gl, const float* d_real, const float* g, const float* norms,
                             float* g_d_real, float* g_d_fake, float* g_g,
                             int B, size_t per, float drift, float lambda, float target, void* stream);
+/* The reference's other loss types (losses.py:47-60 generator, 82-101 critic), on two score vectors a, b of
+ * length B: loss[0] = value, ga/gb = its gradient w.r.t. a and b for an upstream gradient of one.
+ *   kind 1 hinge        mean relu(1 - a) + mean relu(1 + b)
+ *        2 rsgan        mean softplus(-(a - b))
+ *        3 rasgan       (mean softplus(-(a - mean b)) + mean softplus(b - mean a)) / 2
+ *        4 rahinge      (mean relu(1 - (a - mean b)) + mean relu(1 + (b - mean a))) / 2
+ *        5 wgan_theirs  mean b - mean a + eps (mean a + mean b)^2      (score part)
+ *        6              relu(mean a - mean b)                          (wgan_theirs' gain on its penalty)
+ * Critic: a = D(real), b = D(fake).  The generator's relativistic losses are the same functions with
+ * a = D(fake), b = D(real).  eps is used by kind 5 only. */
+int eeggan_score_loss(int kind, const float* a, const float* b, int B, float eps, float* loss, float* ga,
+                      float* gb, void* stream);
+/* out[i] = s[0] * v[i]: a stored loss gradient times the upstream scalar gradient (device scalar). */
+int eeggan_scale_by_scalar(const float* s, const float* v, float* out, size_t n, void* stream);
+/* The gradient penalty alone (losses.py:113-118): loss[0] = lambda/target^2 * mean(p_b^2) with
+ * p_b = |g_b|_2 - target, or relu(|g_b|_2 - target) when one_sided (wgan_theirs).  g is [B, per];
+ * norms[B] is written for the backward, which returns g_g = d loss / d g times gl[0]. */
+int eeggan_grad_penalty_fwd(const float* g, float* norms, float* loss, int B, size_t per, float lambda,
+                            float target, int one_sided, void* stream);
+int eeggan_grad_penalty_bwd(const float* gl, const float* g, const float* norms, float* g_g, int B,
+                            size_t per, float lambda, float target, int one_sided, void* stream);
 /* out[0] = scale * mean(v[0..n))  (generator loss -mean(d_fake): scale = -1). */
 int eeggan_mean_scale(const float* v, float* out, int n, float scale, void* stream);
 /* out[i] = gl[0] * scale / n  for i in [0,n): backward of eeggan_mean_scale. */
@@ -257,6 +278,10 @@ int eeggan_adam_step(const eeggan_adam_tensor* table, int ntensors,
 /* p[k] = g[k] for every tensor of the table (m, v, step unused): packs gradients into the slices
  * of one flat bucket for a single all-reduce. */
 int eeggan_multi_copy(const eeggan_adam_tensor* table, int ntensors, void* stream);
+/* p[k] = alpha * p[k] + beta * g[k] for every tensor of the table (m, v, step unused): the running average of
+ * the generator's weights the reference keeps for its sample outputs (plugins.py:305-307: alpha = old_weight,
+ * beta = 1 - old_weight). */
+int eeggan_multi_axpby(const eeggan_adam_tensor* table, int ntensors, float alpha, float beta, void* stream);
 
 /* ---- 1-D sliced Wasserstein distance (SlicedWDistance, plugins.py:383-395, 426-451) -----------------
  * The metric of the reference's evaluation plugin, on the device.  Per pyramid level:

@@ -389,6 +389,77 @@ def g_loss_wgan(dp, ds, gp_, gs, z, depth, alpha, cfg, src_d, src_g):
     return -d_fake.mean(), dict(fake=fake, d_fake=d_fake)
 
 
+def critic_score_loss(loss_type, d_real, d_fake, drift_eps):
+    """The score terms of losses.py:82-101 -> (loss, gain on the penalty or None for a gain of one)."""
+    F = torch.nn.functional
+    ones, zeros = torch.ones_like(d_real), torch.zeros_like(d_real)
+    if loss_type == "hinge":
+        return F.relu(1.0 - d_real).mean() + F.relu(1.0 + d_fake).mean(), None
+    if loss_type == "rsgan":
+        return F.binary_cross_entropy_with_logits(d_real - d_fake, ones), None
+    if loss_type == "rasgan":
+        return (F.binary_cross_entropy_with_logits(d_real - d_fake.mean(), ones)
+                + F.binary_cross_entropy_with_logits(d_fake - d_real.mean(), zeros)) / 2.0, None
+    if loss_type == "rahinge":
+        return (torch.mean(F.relu(1.0 - (d_real - d_fake.mean())))
+                + torch.mean(F.relu(1.0 + (d_fake - d_real.mean())))) / 2, None
+    if loss_type == "wgan_theirs":
+        f, r = d_fake.mean(), d_real.mean()
+        return f - r + (f + r) ** 2 * drift_eps, F.relu(r - f)
+    if loss_type == "wgan_gp":
+        return d_fake.mean() - d_real.mean() + (d_real ** 2).mean() * drift_eps, None
+    raise ValueError("Invalid loss type")
+
+
+def d_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, mix, src_d, src_g,
+               drift_eps=1e-3, grad_lambda=10.0, target=1.0):
+    """losses.py:73-120 for every loss type.  Call order of the stochastic layers: D(real), G(z) without
+    graph, D(fake), and D(x_hat) unless the penalty is skipped (grad_lambda == 0, or wgan_theirs' gain is zero)."""
+    d_real, _ = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
+    with torch.no_grad():
+        fake = generator_forward(gp_, gs, z, depth, alpha, cfg, src_g)
+    d_fake, _ = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
+    loss, gain = critic_score_loss(loss_type, d_real.reshape(-1), d_fake.reshape(-1), drift_eps)
+    if grad_lambda == 0 or (gain is not None and float(gain) == 0.0):
+        return loss, dict(d_real=d_real, d_fake=d_fake, fake=fake, gain=gain)
+    x_hat = (mix * real.detach() + (1.0 - mix) * fake.detach()).requires_grad_(True)
+    pred, _ = discriminator_forward(dp, ds, x_hat, depth, alpha, cfg, src_d)
+    g = torch.autograd.grad(pred, x_hat, torch.ones_like(pred), create_graph=True,
+                            retain_graph=True)[0].reshape(real.shape[0], -1)
+    pen = g.norm(p=2, dim=1) - target
+    if loss_type == "wgan_theirs":
+        pen = torch.relu(pen)
+    pen_loss = (pen ** 2).mean() * grad_lambda / (target ** 2)
+    loss = loss + (pen_loss if gain is None else gain * pen_loss)
+    return loss, dict(d_real=d_real, d_fake=d_fake, fake=fake, gain=gain, gp_grad=g)
+
+
+def g_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, src_d, src_g):
+    """losses.py:40-60 (no feature matching, no random multiplier).  Call order: G(z), D(fake), and for the
+    relativistic losses D(real) without graph."""
+    F = torch.nn.functional
+    fake = generator_forward(gp_, gs, z, depth, alpha, cfg, src_g)
+    d_fake, _ = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
+    d_fake = d_fake.reshape(-1)
+    if loss_type == "hinge" or loss_type.startswith("wgan"):
+        return -d_fake.mean(), dict(fake=fake, d_fake=d_fake)
+    with torch.no_grad():
+        d_real, _ = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
+    d_real = d_real.reshape(-1)
+    ones, zeros = torch.ones_like(d_fake), torch.zeros_like(d_fake)
+    if loss_type == "rsgan":
+        loss = F.binary_cross_entropy_with_logits(d_fake - d_real, ones)
+    elif loss_type == "rasgan":
+        loss = (F.binary_cross_entropy_with_logits(d_fake - d_real.mean(), ones)
+                + F.binary_cross_entropy_with_logits(d_real - d_fake.mean(), zeros)) / 2.0
+    elif loss_type == "rahinge":
+        loss = (torch.mean(F.relu(1.0 + (d_real - torch.mean(d_fake))))
+                + torch.mean(F.relu(1.0 - (d_fake - torch.mean(d_real))))) / 2
+    else:
+        raise ValueError("Invalid loss type")
+    return loss, dict(fake=fake, d_fake=d_fake, d_real=d_real)
+
+
 # --------------------------------------------------------------------------- schedule
 MINIBATCH_OVERRIDE = {0: 256, 1: 256, 2: 128, 3: 128, 4: 48, 5: 32, 6: 32, 7: 32}  # plugins.py:29-30
 

@@ -536,7 +536,7 @@ def test_full_step_fixture(dev):
 
 
 def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=True, B=8, shard=None, order=None,
-               jitter=0.0):
+               jitter=0.0, loss_type="wgan_gp", seen=None):
     """Two training steps at depth 2 with the noise off and fixed mixing factors (so that every
     variant sees the same random inputs).  Returns the weights, Adam's moments and step counts.
     ``parts``: the critic loss can be asked for its independent parts (a graph trainer then runs them as two
@@ -570,7 +570,7 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=T
             m.strength = 0
     opt_g = Adam(g.parameters(), lr, **config.ADAM)
     opt_d = Adam(d.parameters(), lr, **config.ADAM)
-    d_loss_fn, g_loss_fn = config.loss_closures()
+    d_loss_fn, g_loss_fn = config.loss_closures(loss_type=loss_type)
 
     class _DS:
         model_depth, alpha = depth, 1.0
@@ -587,6 +587,8 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=T
         g.alpha = d.alpha = alpha
         tr.train()
     torch.cuda.synchronize()
+    if seen is not None:  # which form the critic iteration was captured in
+        seen["critic"] = type(getattr(tr, "_d_parts", None)).__name__
     out = {}
     for tag, net, opt in (("G", g, opt_g), ("D", d, opt_d)):
         for k, p in net.named_parameters():

@@ -503,6 +503,112 @@ def block_fixture(out_dir, seed=21):
     print("blocks.npz:", len(fx), "arrays")
 
 
+# ------------------------------------------------------------------------------------------ other loss types
+def loss_types_fixture(out_dir):
+    """The reference's critic and generator losses for every loss type (losses.py:40-120) at depth 1, B = 8, in
+    fp64: loss values and all parameter gradients, with the oracle held to them at 1e-9.  ``wgan_theirs`` is
+    recorded twice: once with its penalty gain above zero and once at zero (the reference then skips the
+    interpolates' pass)."""
+    depth, alpha, batch = 1, 1.0, 8
+    T = cfgmod.seq_len(depth)
+    fx = {"depth": np.array(depth), "alpha": np.array(alpha), "model_seed": np.array(cfgmod.RANDOM_SEED)}
+    cases = [("hinge", 201), ("rsgan", 202), ("rasgan", 203), ("rahinge", 204), ("wgan_gp", 205)]
+    found = {}
+    for seed in range(206, 260):  # wgan_theirs: one seed for each sign of mean D(real) - mean D(fake)
+        cases_try = ("wgan_theirs", seed)
+        g, d = build_pair(cfgmod.RANDOM_SEED)
+        g, d = g.double(), d.double()
+        g.depth = d.depth = depth
+        rng = np.random.default_rng(seed)
+        real = torch.from_numpy(O.synthetic_eeg(batch, cfgmod.NUM_CHANNELS, T, rng)).double()
+        torch.manual_seed(seed)
+        z = torch.randn(batch, cfgmod.LATENT_SIZE).double()
+        np.random.seed(seed + 1)
+        with torch.no_grad():
+            gain = float(torch.relu(d(real)[0].mean() - d(g(z)[0]["x"])[0].mean()))
+        key = "on" if gain > 0 else "off"
+        if key not in found:
+            found[key] = cases_try
+        if len(found) == 2:
+            break
+    cases += [("wgan_theirs", found["on"][1]), ("wgan_theirs", found["off"][1])]
+    names = []
+    for loss_type, seed in cases:
+        rng = np.random.default_rng(seed)
+        real32 = torch.from_numpy(O.synthetic_eeg(batch, cfgmod.NUM_CHANNELS, T, rng))
+        torch.manual_seed(seed)
+        z32 = torch.randn(batch, cfgmod.LATENT_SIZE)
+        mix32 = torch.rand(batch, 1, 1)
+
+        def run_ref(dtype):
+            g, d = build_pair(cfgmod.RANDOM_SEED)
+            g, d = g.to(dtype), d.to(dtype)
+            g.depth = d.depth = depth
+            g.alpha = d.alpha = alpha
+            ga, da = GAdapter(g), DAdapter(d)
+            real, z, mix = real32.to(dtype), z32.to(dtype), mix32.to(dtype)
+            np.random.seed(seed + 1)
+            orig = ref_losses.get_mixing_factor
+            ref_losses.get_mixing_factor = lambda b: mix
+            # (the reference caches float32 targets for its BCE terms, losses.py:21-32; a run is in one dtype throughout)
+            ref_losses.one, ref_losses.zero = torch.ones(batch).to(dtype), torch.zeros(batch).to(dtype)
+            try:
+                d_loss = ref_losses.discriminator_loss(da, ga, {"x": real}, {"z": z}, loss_type, 1e-3, 10.0, 1.0)
+            finally:
+                ref_losses.get_mixing_factor = orig
+            d_loss.backward()
+            d_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in d.named_parameters()}
+            np.random.seed(seed + 2)
+            g_loss = ref_losses.generator_loss(da, ga, {"x": real}, {"z": z}, loss_type, False, 0.0)
+            g_loss.backward()
+            g_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
+            return g, d, real, z, mix, d_loss, d_grads, g_loss, g_grads
+
+        _, _, _, _, _, d_loss32, d_grads32, g_loss32, g_grads32 = run_ref(torch.float32)
+        g, d, real, z, mix, d_loss, d_grads, g_loss, g_grads = run_ref(torch.float64)
+        # the oracle on the same draws
+        gp, gs = to_oracle(g, torch.float64)
+        dp, ds = to_oracle(d, torch.float64)
+        for p in list(gp.values()) + list(dp.values()):
+            p.requires_grad_(True)
+        cfg = O.NetConfig()
+        np.random.seed(seed + 1)
+        src = O.DropSource("numpy")
+        ol, info = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+        og = dict(zip(dp.keys(), torch.autograd.grad(ol, list(dp.values()), allow_unused=True)))
+        assert rel(ol, d_loss) < 1e-9, (loss_type, "d_loss", rel(ol, d_loss))
+        for k, v in d_grads.items():
+            assert (v is None) == (og[k] is None) and (v is None or rel(og[k], v) < 1e-9), (loss_type, k)
+        np.random.seed(seed + 2)
+        src = O.DropSource("numpy")
+        ol, _ = O.g_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, src, src)
+        og = dict(zip(gp.keys(), torch.autograd.grad(ol, list(gp.values()), allow_unused=True)))
+        assert rel(ol, g_loss) < 1e-9, (loss_type, "g_loss", rel(ol, g_loss))
+        for k, v in g_grads.items():
+            assert (v is None) == (og[k] is None) and (v is None or rel(og[k], v) < 1e-9), (loss_type, k)
+        gain = info.get("gain")
+        name = loss_type if loss_type != "wgan_theirs" else ("wgan_theirs_on" if float(gain) > 0 else "wgan_theirs_off")
+        names.append(name)
+        fx[f"{name}.seed"] = np.array(seed)
+        fx[f"{name}.real"], fx[f"{name}.z"], fx[f"{name}.mix"] = real.float().numpy(), z.float().numpy(), mix.float().numpy()
+        fx[f"{name}.d_loss"], fx[f"{name}.g_loss"] = d_loss.detach().numpy(), g_loss.detach().numpy()
+        fx[f"{name}.d_loss32"], fx[f"{name}.g_loss32"] = d_loss32.detach().numpy(), g_loss32.detach().numpy()
+        for tag, grads, grads32 in (("d", d_grads, d_grads32), ("g", g_grads, g_grads32)):
+            for k, v in grads.items():
+                if v is None:
+                    fx[f"{name}.{tag}_none.{k}"] = np.array(1)
+                else:
+                    fx[f"{name}.{tag}_sub.{k}"] = subsample(v)
+                    fx[f"{name}.{tag}_norm.{k}"] = np.array(float(v.norm()))
+                    if grads32[k] is not None:  # (wgan_theirs at a gain near zero may skip the penalty in one precision)
+                        fx[f"{name}.{tag}_sub32.{k}"] = subsample(grads32[k])
+                        fx[f"{name}.{tag}_noise.{k}"] = np.array(rel(grads32[k], v))
+        ref_losses.one = ref_losses.zero = None
+        print(f"loss type {name}: seed {seed}, d_loss {float(d_loss):.6f}, g_loss {float(g_loss):.6f}, oracle matches")
+    fx["names"] = np.array(names)
+    np.savez_compressed(os.path.join(out_dir, "loss_types.npz"), **fx)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -520,6 +626,7 @@ def main():
         "step": lambda: step_fixture(args.out),
         "dataset": lambda: dataset_fixture(args.out),
         "blocks": lambda: block_fixture(args.out),
+        "loss_types": lambda: loss_types_fixture(args.out),
     }
     for k, fn in jobs.items():
         if not args.only or k in args.only.split(","):
