@@ -3,8 +3,9 @@
 //   G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal  == [B,Cin] x [Cin, Cout*KT]
 //   D tail: Conv1d(k=KT, pad=0)    on a length-KT signal == [B,Cin*KT] x [Cin*KT, Cout]
 // At the path's sizes (B <= 512, Cin = Cout = 256, KT = 32) they move the 8.4 MB weight
-// once and do ~0.1-2 GFLOP: bandwidth/latency-bound, so they are plain fp32 VALU kernels
-// with the weight streamed coalesced and the small operand broadcast from LDS.
+// once and do ~0.1-2 GFLOP: bandwidth/latency-bound, so most of them are plain fp32 VALU kernels
+// with the weight streamed coalesced and the small operand broadcast from LDS (the head's forward pass and the
+// tail's input gradient run on the matrix cores).
 #include "common.h"
 
 #include <cstdlib>
@@ -369,6 +370,80 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---- the tail layer's input gradient on the matrix cores -----------------------------------------------------------
+// gx[B, Kd] = gy[B, Cout] w[Cout, Kd] has a long OUTPUT axis (Kd = 8192 columns) and a short reduction (Cout): every
+// workgroup owns 32 columns and streams its 32-column strip of the weights once, in full 128-byte rows, through
+// v_mfma_f32_32x32x2_f32 (fp32 operands, no splitting: ~0.3 GFLOP per launch): 7-8 us against 13 us for the
+// vector-ALU kernel below at 32-64 samples.  acc = mfma(a, b, acc) adds a (row i = this lane's first-operand index,
+// lane & 31) times b (column j = lane & 31) for the reduction index the lane half (lane >> 5) stands for; the result
+// has column j in lane j and row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) in register r.  The four waves of a workgroup
+// split the reduction and add their tiles through LDS.  (Measured and left on the vector ALUs: the forward pass
+// as a split-reduction GEMM -- its second launch, which adds the partial sums, makes it 16.1 against 13.7 us -- and
+// the weight gradient, whose accumulator layout stores 128-byte pieces of 256 rows where the vector kernel
+// stores 4 KB runs: 9.6 / 15.6 against 8.1 / 12.6 us at 32 / 64 samples.)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// sum of the four waves' accumulator tiles (NT tiles each); every thread gets the sums of its 4 NT values back in
+// out[]: value index v = tile * 1024 + r * 64 + lane for v = threadIdx.x + 256 i
+template <int NT>
+__device__ __forceinline__ void cross_wave_sum(const f32x16 (&acc)[NT], float* red, float (&out)[4 * NT]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) {
+        const int v = threadIdx.x + 256 * i;
+        out[i] = (red[v] + red[NT * 1024 + v]) + (red[2 * NT * 1024 + v] + red[3 * NT * 1024 + v]);
+    }
+    __syncthreads();
+}
+
+// input gradient: gx[b][k] = in_scale * sum_co gy[b][co] w[co][k]; grid Kd / 32, a workgroup owns 32 columns k,
+// its waves a quarter of the output channels each
+__global__ __launch_bounds__(256) void tail_dgrad_mfma_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                              float* __restrict__ gx, int B, int Kd, int Cout,
+                                                              float in_scale) {
+    __shared__ float red[4 * 2 * 1024];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int k0 = blockIdx.x * 32;
+    const int cq = Cout / 4, c0 = wave * cq;  // (Cout % 32 == 0)
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int ba = b0 + l31 < B ? b0 + l31 : B - 1, bb = b0 + 32 + l31 < B ? b0 + 32 + l31 : B - 1;
+        const float* ga = gy + (long long)ba * Cout + c0 + 4 * h;
+        const float* gb = gy + (long long)bb * Cout + c0 + 4 * h;
+        const float* wp = w + (long long)(c0 + 4 * h) * Kd + k0 + l31;
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        for (int c = 0; c < cq; c += 8) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(ga + c);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(gb + c);
+            float wv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wv[e] = wp[(long long)(c + e) * Kd];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[e], wv[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[e], wv[e], acc[1], 0, 0, 0);
+            }
+        }
+        float sums[8];
+        cross_wave_sum<2>(acc, red, sums);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = threadIdx.x + 256 * i;
+            const int t = v >> 10, r = (v >> 6) & 15, ln = v & 63;
+            const int b = b0 + 32 * t + acc_row(r, ln >> 5);
+            if (b < B) gx[(long long)b * Kd + k0 + (ln & 31)] = sums[i] * in_scale;
+        }
+    }
+}
+
+bool tail_mfma_shape(int Kd, int Cout) { return Kd % 32 == 0 && Cout % 32 == 0; }
+
 int check_ht(const char* what, int B, int Cin, int Cout, int KT) {
     EEGGAN_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && KT > 0, "%s: non-positive dimension", what);
     EEGGAN_REQUIRE(B <= 4096, "%s: batch %d above the supported 4096", what, B);
@@ -431,6 +506,11 @@ extern "C" int eeggan_tail_dgrad(const float* gy, const float* w, float* gx, int
     EEGGAN_REQUIRE(gy && w && gx, "tail_dgrad: null pointer");
     const int Kd = Cin * KT;
     EEGGAN_REQUIRE(Kd % 4 == 0, "tail_dgrad: Cin*KT = %d must be a multiple of 4", Kd);
+    if (tail_mfma_shape(Kd, Cout) && (reinterpret_cast<uintptr_t>(gy) & 15) == 0) {
+        hipLaunchKernelGGL(tail_dgrad_mfma_kernel, dim3(Kd / 32), dim3(256), 0, as_stream(stream), gy, w, gx, B, Kd, Cout,
+                           in_scale);
+        return check_launch("tail_dgrad");
+    }
     EEGGAN_REQUIRE(Cout <= 1024, "tail_dgrad: Cout %d above the supported 1024 (LDS tile)", Cout);
     const size_t lds = ((size_t)((8 * Cout + 3) & ~3) + 4 * 8 * 64 * 4) * sizeof(float);
     hipLaunchKernelGGL(tail_dgrad_kernel, dim3((Kd + 255) / 256, (B + 7) / 8), dim3(256), lds, as_stream(stream), gy, w,
