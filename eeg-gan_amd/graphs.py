@@ -79,7 +79,7 @@ class _SplitCriticIteration:
             loss = d_loss_fn(dis, gen, {"x": trainer._real}, {"z": trainer._z}, part=part,
                              zero_grad=(part == self.parts[0]))
             with ops.direct_weight_grads(trainer.direct_grads, deferred=True):
-                loss.backward()
+                loss.backward(trainer._seed)  # (a persistent one: backward() alone fills a fresh one per replay)
             # gradients that took autograd's own route (the full-length layer's): kept per chain
             stash = [(p, p.grad) for p in dis.parameters() if p.grad is not None]
             for p, _ in stash:
@@ -280,7 +280,14 @@ class GraphedTrainer(Trainer):
         if sync is not None and not (hasattr(sync, "pack") and hasattr(sync, "reduce") and hasattr(sync, "apply")):
             raise NotImplementedError("GraphedTrainer: grad_sync must offer pack/reduce/apply phases")
         bucketed = sync is not None and getattr(sync, "bucketed", True)
-        self._real, self._z = real.clone(), z.clone()
+        # static inputs: reals and (when they are made ahead of the critic iterations) fakes back to back in one
+        # buffer, so that the stacked critic pass reads them without a concatenation
+        n = real.shape[0]
+        self._pair = torch.empty((2 * n,) + tuple(real.shape[1:]), device=real.device, dtype=real.dtype)
+        self._real = self._pair[:n]
+        self._real.copy_(real)
+        self._z = z.clone()
+        self._seed = torch.ones((), device=real.device, dtype=torch.float32)  # d loss / d loss
         snap = _snapshot([self.discriminator, self.generator], [self.optimizer_d, self.optimizer_g])
 
         # The generator does not change during the critic iterations of a step (reference
@@ -298,7 +305,8 @@ class GraphedTrainer(Trainer):
                     return self.generator({"z": self._zall})[0]["x"]
 
             self._fakes_call = GraphedCall(all_fakes)
-            self._fake = self._fakes_call.out[:z.shape[0]].clone()
+            self._fake = self._pair[n:]
+            self._fake.copy_(self._fakes_call.out[:n])
             d_loss_fn = lambda dis, gen, r, zz, **kw: self.d_loss(dis, gen, r, zz, fake=self._fake, **kw)  # noqa: E731
 
         def iteration(loss_fn, module, optimizer):
@@ -308,7 +316,7 @@ class GraphedTrainer(Trainer):
             def fwd_bwd():
                 loss = loss_fn(self.discriminator, self.generator, {"x": self._real}, {"z": self._z})
                 with ops.direct_weight_grads(self.direct_grads):
-                    loss.backward()
+                    loss.backward(self._seed)
                 if bucketed:
                     box["bucket"] = sync.pack(module)
                 else:
@@ -387,9 +395,10 @@ class GraphedTrainer(Trainer):
                     raise RuntimeError("GraphedTrainer: the batch shape changed inside a step")
             self.cur_nimg += n
             self._real.copy_(real)
-            self._z.copy_(zs[i])
-            if fakes is not None:
+            if fakes is not None:  # (the iteration's latents went into the fakes already)
                 self._fake.copy_(fakes[i * n:(i + 1) * n])
+            else:
+                self._z.copy_(zs[i])
             d_loss = self._replay(self._d_parts)
         self._z.copy_(zs[repeats])
         g_loss = self._replay(self._g_parts)

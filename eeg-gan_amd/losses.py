@@ -45,6 +45,18 @@ def get_zero(batch_size):
     return zero
 
 
+def _stacked(real_x, fake_x):
+    """[reals; fakes] as one batch: without a copy when the two already lie back to back in one buffer (a graph
+    trainer keeps its static inputs that way), a concatenation otherwise."""
+    if (real_x.shape == fake_x.shape and real_x.dtype == fake_x.dtype and real_x.is_contiguous()
+            and fake_x.is_contiguous() and not real_x.requires_grad and not fake_x.requires_grad
+            and real_x.untyped_storage().data_ptr() == fake_x.untyped_storage().data_ptr()
+            and fake_x.storage_offset() == real_x.storage_offset() + real_x.numel()):
+        return real_x.as_strided((2 * real_x.shape[0],) + tuple(real_x.shape[1:]), real_x.stride(),
+                                 real_x.storage_offset())
+    return torch.cat([real_x, fake_x])
+
+
 def calc_grad(x_hat, pred_hat):
     """d(sum pred_hat)/d(x_hat) with a graph, so it can be differentiated again.  Weight
     gradients are not formed in this pass (only the input gradient is asked for)."""
@@ -152,7 +164,7 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
             return ops.wgan_gp_d_loss(zeros, score, nothing, 0.0, 0.0, iwass_target)
         if part in (None, "scores"):
             with layers.batch_segments(2):
-                scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+                scores, _, _ = dis({"x": _stacked(real_x, fake_x)})
             if part == "scores":
                 nothing = get_zero(n).view(n, 1)  # no penalty: lambda = 0 on an all-zero "gradient"
                 return ops.wgan_gp_d_loss_stacked(scores, nothing, iwass_drift_epsilon, 0.0, iwass_target)
@@ -206,7 +218,7 @@ def _other_discriminator_loss(dis, gen, real, z, loss_type, drift, grad_lambda, 
             fake_x = fake
         if part != "penalty":
             with layers.batch_segments(2):
-                scores, _, _ = dis({"x": torch.cat([real_x, fake_x])})
+                scores, _, _ = dis({"x": _stacked(real_x, fake_x)})
             scores = scores.reshape(-1)
             d_real, d_fake = scores[:n], scores[n:]
     else:  # the reference's order of passes (and of noise draws): D(real), G(z), D(fake), D(x_hat)
