@@ -37,8 +37,8 @@ STEP_GFLOP_PER_SAMPLE = {7: 33.41, 0: 1.183}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 steps are ~1.7 s at the headline configuration)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--drop-mode", default="device", choices=["device", "numpy"],
                     help="'device': GDrop noise drawn on the GPU (same distribution); "
                          "'numpy': the reference's host RNG stream")
@@ -58,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_inputs=False):
+def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_inputs=False, force_dist=False):
     from eeggan_amd import config, layers
     from eeggan_amd.optim import Adam
     from eeggan_amd.parallel import DataParallelStep
@@ -96,7 +96,7 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_
     cls = Trainer if (eager or layers.get_drop_mode() != "device") else GraphedTrainer
     tr = cls(d, g, d_loss, g_loss, _DS(), latents(), 0, opt_g, opt_d)
     tr.dataiter = reals()
-    tr.grad_sync = DataParallelStep() if world > 1 else None
+    tr.grad_sync = DataParallelStep(always_bucket=force_dist) if (world > 1 or force_dist) else None
     return tr
 
 
@@ -293,7 +293,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # EEGGAN_FORCE_DIST=1 takes the multi-rank path (process group, gradient buckets, collectives between graph
+    # replays) with however many ranks there are, one included: a rehearsal of that path on a one-GPU box
+    force_dist = os.environ.get("EEGGAN_FORCE_DIST") is not None
+    if world > 1 or force_dist:
         import torch.distributed as dist
         # EEGGAN_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
         backend = os.environ.get("EEGGAN_DIST_BACKEND", "nccl")
@@ -314,7 +317,8 @@ def main():
     if args.dtype == "bf16":
         from eeggan_amd import ops
         ops.set_precision("bf16")
-    tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs)
+    tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs,
+                      force_dist=force_dist)
     if args.per_iteration_fakes:
         tr.batch_fakes = False
 
@@ -337,7 +341,7 @@ def main():
         print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
         torch.cuda.synchronize()
         tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, eager=True,
-                          host_inputs=args.host_inputs)
+                          host_inputs=args.host_inputs, force_dist=force_dist)
     for _ in range(args.warmup):
         tr.train()
     barrier()
