@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the conv layers' matrix products: f32 (fp32 products, the headline) or bf16 "
                          "(operands rounded to bf16, fp32 accumulation and storage: the large-batch mode, looser bounds)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "bf16"],
+                    help="storage of the wide activations between the conv layers and of their gradients: f32 (the "
+                         "headline) or bf16 (large-batch mode; implies --dtype bf16; signals, the 32-sample stage, weights, "
+                         "weight gradients and optimizer state stay float32)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="reals start in pinned host memory and cross PCIe inside the timed region "
                          "(a side measurement; the headline value keeps them resident in HBM)")
@@ -111,6 +115,9 @@ def conv_roofline(dev, batch, T):
     from eeggan_amd import ops
     C, K = 64, 3
     x = torch.randn(batch, C, T, device=dev)
+    esize = 4.0
+    if ops.get_storage() == "bf16":  # the layer's input and output are bfloat16 in this mode
+        x, esize = x.bfloat16(), 2.0
     w = torch.randn(C, C, K, device=dev)
     b = torch.randn(C, device=dev)
     r = torch.rand(batch, C, device=dev) + 0.5
@@ -142,8 +149,8 @@ def conv_roofline(dev, batch, T):
     # 2 x FETCH_SIZE + WRITE_SIZE = 2 x 9822.6 KiB + 15360 KiB (gfx950 tallies 128-byte read requests at
     # 64 bytes); the algorithmic figure is 31.5 MB: input + output once, weights, multipliers.  Only valid
     # for the profiled shape.
-    traffic = (2 * 9822.5625 + 15360.0) * 1024 if (batch, T) == (32, 1920) else None
-    algorithmic_bytes = 4.0 * (2 * batch * C * T + C * C * K + C + batch * C)
+    traffic = (2 * 9822.5625 + 15360.0) * 1024 if (batch, T, esize) == (32, 1920, 4.0) else None
+    algorithmic_bytes = esize * 2 * batch * C * T + 4.0 * (C * C * K + C + batch * C)
     # The kernel forms every fp32 product from three bf16 pieces per operand (six bf16 MFMAs per 16
     # reduction indices, fp32-exact to 2^-24).  `achieved`/`frac` price the ALGORITHMIC fp32 flops against
     # the fp32 matrix peak (the arithmetic type of the path); `pipe_frac` prices the six-fold executed
@@ -158,7 +165,8 @@ def conv_roofline(dev, batch, T):
         ceiling = min(BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS * (flops / algorithmic_bytes) / 1e3)
         hbm_bound = ceiling < BF16_MFMA_PEAK_TFLOPS
         return {"bound": "hbm" if hbm_bound else "mfma",
-                "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop), bf16 products" % batch,
+                "kernel": "conv_ws_kernel<K=3> (64->64 ch, k=3, T=1920, B=%d, fused bias+lrelu+drop), bf16 products, %s tensors"
+                          % (batch, "bfloat16" if esize == 2.0 else "float32"),
                 "achieved": round(algorithmic_bytes / back_to_back / 1e9, 1) if hbm_bound else round(achieved, 3),
                 "peak": HBM_PEAK_GBS if hbm_bound else BF16_MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round(achieved / ceiling, 4), "traffic": None, "avg_launch_us": round(back_to_back * 1e6, 2),
@@ -314,9 +322,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     from eeggan_amd import layers
     layers.set_drop_mode(args.drop_mode)
+    if args.storage == "bf16":
+        args.dtype = "bf16"
     if args.dtype == "bf16":
         from eeggan_amd import ops
         ops.set_precision("bf16")
+        if args.storage == "bf16":
+            ops.set_storage("bf16")
     tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, args.eager, args.host_inputs,
                       force_dist=force_dist)
     if args.per_iteration_fakes:
@@ -364,7 +376,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (reals copied from pinned host memory each iteration)" if args.host_inputs else ""),
             "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha={args.alpha:g}, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
-                       "parallelism": f"dp{world}", "drop_noise": args.drop_mode,
+                       "parallelism": f"dp{world}", "drop_noise": args.drop_mode, "activation_storage": args.storage,
                        "launch": type(tr).__name__},
         }
         out["roofline"] = conv_roofline(dev, args.batch, T)

@@ -88,6 +88,17 @@ SIGNATURES = {
     "eeggan_scale_by_scalar": (_i, [_f, _f, _f, _sz, _st]),
     "eeggan_grad_penalty_fwd": (_i, [_f, _f, _f, _i, _sz, _fl, _fl, _i, _st]),
     "eeggan_grad_penalty_bwd": (_i, [_f, _f, _f, _f, _i, _sz, _fl, _fl, _i, _st]),
+    # typed forms (bfloat16 activation storage): the float32 signatures plus storage flags
+    "eeggan_conv1d_t": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _fl, _f, _f, _f, _fl, _i, _i, _st]),
+    "eeggan_conv1d_pixelnorm_t": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _fl, _i, _st]),
+    "eeggan_resample_t": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "eeggan_resample_quads_t": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "eeggan_lrelu_drop_bwd_t": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
+    "eeggan_pixelnorm_drop_fwd_t": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
+    "eeggan_pixelnorm_drop_bwd_t": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
+    "eeggan_axpby_t": (_i, [_f, _fl, _f, _fl, _f, _sz, _i, _st]),
+    "eeggan_blend_t": (_i, [_f, _f, _f, _i, _f, _sz, _i, _st]),
+    "eeggan_cast": (_i, [_f, _f, _sz, _i, _i, _st]),
 }
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_MASK = 0, 1, 2, 3

@@ -28,6 +28,54 @@ int check_launch(const char* what);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- activation storage types -----------------------------------------------------------------------
+// Activations live in memory as float32 or, in the bf16 storage mode, as bfloat16; arithmetic is always
+// float32.  A kernel that prefetches keeps the RAW loaded words in registers (raw4 / raw1: no instruction
+// consumes the load, so nothing waits for it) and widens them where the value is used (widen).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool BF>
+struct ActT {
+    typedef float T;
+    typedef f32x4 raw4;
+    typedef float raw1;
+};
+template <>
+struct ActT<true> {
+    typedef __bf16 T;
+    typedef u32x2 raw4;
+    typedef unsigned short raw1;
+};
+__device__ __forceinline__ f32x4 ld_raw4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ u32x2 ld_raw4(const __bf16* p) { return *reinterpret_cast<const u32x2*>(p); }
+__device__ __forceinline__ float ld_raw1(const float* p) { return *p; }
+__device__ __forceinline__ unsigned short ld_raw1(const __bf16* p) { return *reinterpret_cast<const unsigned short*>(p); }
+__device__ __forceinline__ f32x4 widen(f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 widen(u32x2 u) {
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, u[0] << 16);
+    v[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, u[1] << 16);
+    v[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ float widen(float v) { return v; }
+__device__ __forceinline__ float widen(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return ld_raw4(p); }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) { return widen(ld_raw4(p)); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return widen(ld_raw1(p)); }
+// stores round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, f32x4 v) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

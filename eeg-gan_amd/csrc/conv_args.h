@@ -26,6 +26,9 @@ struct ConvArgs {
     float* pn_d;   // ACT_LRELU_PN: per-(sample, time) normaliser output [B, T]
     float pn_eps;
     int wpb;    // weight-stationary kernel: waves per workgroup that take work units
+    // bf16 storage mode: x and mask_y (x_bf16), y and act_aux (y_bf16) hold bfloat16 instead of float32; the
+    // pointers above then address 2-byte elements
+    int x_bf16, y_bf16;
 #ifdef EEGGAN_TRACE
     unsigned long long* trace;  // [4 traced blocks][8 waves][TRACE_STEPS][8] shader-clock stamps
 #endif

@@ -50,7 +50,9 @@ struct XStage {
     f32x4 v[VPT];
     float hv[HPT];
 
-    __device__ __forceinline__ void load(const float* __restrict__ src, const float* __restrict__ mask_y,
+    // (TS: float or __bf16, the storage type of src and mask_y)
+    template <typename TS>
+    __device__ __forceinline__ void load(const TS* __restrict__ src, const TS* __restrict__ mask_y,
                                          const float* __restrict__ mask_drop, float slope, int C, int T,
                                          int ST, int NS, int sub0, int c0, bool vec) {
         const int tid = threadIdx.x;
@@ -69,9 +71,9 @@ struct XStage {
                 if (row < ROWS && c < C && sub < NS && t < T) {
                     const long long off = ((long long)b * C + c) * T + t;
                     if (vec) {
-                        val = *reinterpret_cast<const f32x4*>(src + off);
+                        val = ld4(src + off);
                         if (mask_y) {
-                            const f32x4 my = *reinterpret_cast<const f32x4*>(mask_y + off);
+                            const f32x4 my = ld4(mask_y + off);
                             const float md = mask_drop ? mask_drop[b * C + c] : 1.f;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) val[e] *= md * (my[e] > 0.f ? 1.f : slope);
@@ -81,8 +83,8 @@ struct XStage {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if (t + e < T) {
-                                float u = src[off + e];
-                                if (mask_y) u *= md * (mask_y[off + e] > 0.f ? 1.f : slope);
+                                float u = ld1(src + off + e);
+                                if (mask_y) u *= md * (ld1(mask_y + off + e) > 0.f ? 1.f : slope);
                                 val[e] = u;
                             }
                         }
@@ -105,10 +107,10 @@ struct XStage {
                 float u = 0.f;
                 if (row < ROWS && c < C && sub < NS && t >= 0 && t < T) {
                     const long long off = ((long long)b * C + c) * T + t;
-                    u = src[off];
+                    u = ld1(src + off);
                     if (mask_y) {
                         const float md = mask_drop ? mask_drop[b * C + c] : 1.f;
-                        u *= md * (mask_y[off] > 0.f ? 1.f : slope);
+                        u *= md * (ld1(mask_y + off) > 0.f ? 1.f : slope);
                     }
                 }
                 hv[i] = u;
@@ -163,10 +165,17 @@ struct XStage {
 //   MASK (-1 | 0 | 1): whether the input carries a fused backward mask; -1 decides at run time.  The two-stage
 //   prefetch wants it known at compile time: a branch around the mask loads makes the load counts the waits
 //   are computed from path-dependent, and the waits conservative.
+//   BF (FULL, SPLIT = 1): the activations (x, mask_y, y, act_aux) are bfloat16 in memory (bf16 storage mode).
 template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, int SPLIT = 0, int MASK = -1,
-          int NTHR = 64 * WM * WN * KS>
+          bool BF = false, int NTHR = 64 * WM * WN * KS>
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
+    static_assert(!BF || (FULL && VEC && SPLIT == 1), "bf16 storage: predicate-free form with bf16 products");
+    typedef typename ActT<BF>::T AT;
+    typedef typename ActT<BF>::raw4 R4;
+    typedef typename ActT<BF>::raw1 R1;
+    const AT* const X0 = reinterpret_cast<const AT*>(a.x);
+    const AT* const M0 = reinterpret_cast<const AT*>(a.mask_y);
     constexpr int PAD = (K - 1) / 2;
     constexpr int WROWB = CK * K * 2 + 16;  // SPLIT: bytes per weight row and piece (conflict-free b128 reads)
     constexpr int WLD = SPLIT ? 3 * WROWB / 4 : CK * K + 4;  // LDS floats per weight row of a chunk (fp32 form: conflict-free b128 reads)
@@ -227,9 +236,11 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     // arrive -- a chunk's MFMAs are shorter than a trip to L2 once the products run on the bf16 pipe.
     constexpr bool DEEP = SPLIT;
     struct Stage {
-        f32x4 wv[WV], xv[XV];
-        f32x4 mv[VEC ? XV : 1];  // mask_y values of the activation items (VEC path)
-        float hv[HV], mdv[XV], mhv[HV], mdh[HV];
+        f32x4 wv[WV];
+        R4 xv[XV];
+        R4 mv[VEC ? XV : 1];  // mask_y values of the activation items (VEC path)
+        R1 hv[HV], mhv[HV];
+        float mdv[XV], mdh[HV];
         unsigned okbits;         // bit i: weight item i valid; bit 8+i: activation item i; bit 16+i: halo i
         int p_lim;
         bool x_ok, h_ok;         // the tile-level validity of this thread's items when the step was prefetched
@@ -245,12 +256,12 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     int p_co0 = 0;
     // FULL: per-tile base pointers of this thread's items
     const float* fw[WV];
-    const float* fx = a.x;
-    const float* fh = a.x;
-    const float* fmx = a.x;
-    const float* fmh = a.x;
-    const float* fdx = a.x;
-    const float* fdh = a.x;
+    const AT* fx = X0;
+    const AT* fh = X0;
+    const AT* fmx = X0;
+    const AT* fmh = X0;
+    const float* fdx = a.w;
+    const float* fdh = a.w;
 
     auto setup_tile = [&](int tile) {
         // (a tile past the end -- the two-stage prefetch runs unconditionally -- stages nothing: all of its loads
@@ -280,11 +291,11 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         if (FULL) {
 #pragma unroll
             for (int i = 0; i < WV; ++i) fw[i] = live ? a.w + ((long long)(p_co0 + w_row[i]) * a.Cin) * K + 4 * w_q[i] : a.w;
-            fx = a.x + (x_ok ? x_off : 0);
-            fh = a.x + (h_ok ? h_off : 0);
+            fx = X0 + (x_ok ? x_off : 0);
+            fh = X0 + (h_ok ? h_off : 0);
             if (has_mask) {
-                fmx = a.mask_y + (x_ok ? x_off : 0);
-                fmh = a.mask_y + (h_ok ? h_off : 0);
+                fmx = M0 + (x_ok ? x_off : 0);
+                fmh = M0 + (h_ok ? h_off : 0);
                 if (a.mask_drop) {
                     fdx = a.mask_drop + (x_ok ? x_b * a.Cin + x_row0 : 0);
                     fdh = a.mask_drop + (h_ok ? h_b * a.Cin + h_row0 : 0);
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         s.x_ok = x_ok;
         s.h_ok = h_ok;
         const int ci0 = p_chunk * CK;
-        if (FULL) {
+        if constexpr (FULL) {
             // every address = per-tile base + a wave-uniform offset; a whole-item predicate (tile tail,
             // sample edge) only redirects the base to a valid address, its value is dropped in commit()
             const int wo = ci0 * K;
@@ -321,9 +332,9 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < XV; ++i) {
                 const long long o = x_ok ? xo + (long long)(i * XROWS) * a.T : 0;
-                xv[i] = *reinterpret_cast<const f32x4*>(fx + o);
+                xv[i] = ld_raw4(fx + o);
                 if (has_mask) {  // wave-uniform
-                    mv[VEC ? i : 0] = *reinterpret_cast<const f32x4*>(fmx + o);
+                    mv[VEC ? i : 0] = ld_raw4(fmx + o);
                     mdv[i] = fdx[(x_ok && a.mask_drop) ? ci0 + i * XROWS : 0];  // (without multipliers: any valid address; selected in commit)
                 }
             }
@@ -332,15 +343,15 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 for (int i = 0; i < HV; ++i) {
                     const bool ok = h_ok && h_row0 + i * HROWS < CK;
                     const long long o = ok ? xo + (long long)(i * HROWS) * a.T : 0;
-                    hv[i] = fh[o];
+                    hv[i] = ld_raw1(fh + o);
                     if (has_mask) {
-                        mhv[i] = fmh[o];
+                        mhv[i] = ld_raw1(fmh + o);
                         mdh[i] = fdh[(ok && a.mask_drop) ? ci0 + i * HROWS : 0];
                     }
                 }
             }
             return;
-        }
+        } else {
         okbits = 0;
         if (wvec) {
 #pragma unroll
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 }
             }
         }
+        }
     };
 
     auto commit = [&](const Stage& s, float* buf) {  // registers -> LDS buffer (all consumers of the prefetch live here)
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         const bool x_ok = s.x_ok, h_ok = s.h_ok;
         float* Ws = buf;
         float* Xs = buf + CT * WLD;
-        if (FULL) {
+        if constexpr (FULL) {
             if constexpr (SPLIT) {
                 bf16x4s p[3][3];  // [tap][piece]: this thread's channels 4 (tid & 7) .. + 3 of the chunk
 #pragma unroll
@@ -455,9 +467,9 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < XV; ++i) {
-                f32x4 v = xv[i];
+                f32x4 v = widen(xv[i]);
                 if (has_mask) {
-                    const f32x4 my = mv[VEC ? i : 0];
+                    const f32x4 my = widen(mv[VEC ? i : 0]);
                     const float d = a.mask_drop ? mdv[i] : 1.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? d : d * a.mask_slope;
@@ -470,14 +482,14 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < HV; ++i) {
                     const int row = h_row0 + i * HROWS;
-                    float u = hv[i];
+                    float u = widen(hv[i]);
                     const float d = a.mask_drop ? mdh[i] : 1.f;
-                    if (has_mask) u *= mhv[i] > 0.f ? d : d * a.mask_slope;
+                    if (has_mask) u *= widen(mhv[i]) > 0.f ? d : d * a.mask_slope;
                     if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = h_ok ? u : 0.f;
                 }
             }
             return;
-        }
+        } else {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const bool ok = (okbits >> i) & 1u;
@@ -513,6 +525,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 if (has_mask) u *= mhv[i] > 0.f ? mdh[i] : mdh[i] * a.mask_slope;
                 if (row < CK) Xs[row * XLD + h_n * SUB + (h_side ? 36 : 3)] = ok ? u : 0.f;
             }
+        }
         }
     };
 
@@ -732,7 +745,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             }
                             if (ACT == EEGGAN_ACT_MASK) {
                                 if (VEC) {
-                                    const f32x4 m = *reinterpret_cast<const f32x4*>(a.act_aux + o);
+                                    const f32x4 m = ld4(reinterpret_cast<const AT*>(a.act_aux) + o);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * a.act_param;
                                 } else {
@@ -747,7 +760,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             for (int e = 0; e < 4; ++e) v[e] *= dd;
                             {
                                 if (VEC) {
-                                    if (ok) *reinterpret_cast<f32x4*>(a.y + o) = v;
+                                    if (ok) st4(reinterpret_cast<AT*>(a.y) + o, v);
                                 } else {
 #pragma unroll
                                     for (int e = 0; e < 4; ++e)
@@ -832,11 +845,12 @@ int num_cus() {
 
 namespace {
 
-template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, int SPLIT = 0, int MASK = -1>
+template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, int SPLIT = 0, int MASK = -1,
+          bool BF = false>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
     constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
-    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK>;
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK, BF>;
     // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once per device)
     static std::atomic<int> per_cu_dev[MAX_DEVICES];
     std::atomic<int>& slot = per_cu_dev[current_device()];
@@ -876,6 +890,11 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
         rc = launch_conv_ws(a, K, st);
         if (rc >= 0) return rc;
     }
+    if ((a.x_bf16 || a.y_bf16) && (K != 3 || !a.vec || a.Cout <= 32)) {
+        set_error("conv1d: bfloat16 activations are supported for the predicate-free k = 3 layers and for 1x1 layers "
+                  "with at most 8 channels on one side (K=%d Cin=%d Cout=%d T=%d)", K, a.Cin, a.Cout, a.T);
+        return 1;
+    }
     if (!a.vec) return launch_fwd<K, 64, 2, 32, 2, 2, false>(a, st);
     if (a.Cout <= 32) return launch_fwd<K, 32, 8, 32, 1, 4, true>(a, st);
     const bool full = a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.T % 32 == 0;
@@ -888,6 +907,19 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
         // predicate-free layers: products from bf16 pieces.  The narrow tile is 32 channels x 2 subtiles there (as many
         // tiles as 64 x 1): with the weight chunk as three piece planes that is what still fits twice on a CU.
         const int pieces = product_pieces();
+        if (a.x_bf16 || a.y_bf16) {
+            // bf16 storage: the predicate-free layers with both sides bfloat16 and bf16 products
+            if (!(full && pieces == 1 && a.x_bf16 && a.y_bf16)) {
+                set_error("conv1d: bfloat16 activations need Cin %% 32 == 0, Cout %% 64 == 0, T %% 32 == 0, both sides "
+                          "bfloat16 and the bf16 matrix precision (Cin=%d Cout=%d T=%d)", a.Cin, a.Cout, a.T);
+                return 1;
+            }
+            if (a.mask_y)
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 1, true>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 1, true>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 0, true>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 0, true>(a, st);
+        }
         if (full && pieces == 3) {
             if (a.mask_y)
                 return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 1>(a, st)
@@ -966,6 +998,7 @@ struct WgradArgs {
     int nsplit;
     int iters;    // subtile pairs per split
     int vec;
+    int x_bf16, gy_bf16;  // bf16 storage mode: x / gy and mask_y hold bfloat16 (2-byte elements behind the pointers)
 #ifdef EEGGAN_TRACE
     unsigned long long* trace;  // as ConvArgs::trace
 #endif
@@ -980,9 +1013,16 @@ unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next w
 // SPLIT (FULL, K = 3): the products run on the bf16 matrix pipe, each fp32 operand as the sum of three bf16
 // pieces with the six leading piece products kept (fp32-exact to 2^-24; see conv_ws.hip): 18 MFMAs of 16
 // time steps replace 24 fp32 MFMAs of 2.
-template <int K, bool FULL, int SPLIT = 0>
+// XBF / GBF: x / gy (and mask_y) are bfloat16 in memory.
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
     static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
+    static_assert(!(FULL && (XBF || GBF)) || (SPLIT == 1 && XBF && GBF), "bf16 storage, predicate-free form: bf16 products, both sides");
+    typedef typename ActT<XBF>::T XT;
+    typedef typename ActT<GBF>::T GT;
+    const XT* const X0 = reinterpret_cast<const XT*>(a.x);
+    const GT* const G0 = reinterpret_cast<const GT*>(a.gy);
+    const GT* const M0 = reinterpret_cast<const GT*>(a.mask_y);
     constexpr int PAD = (K - 1) / 2;
     constexpr int NTW = 2;
     constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
@@ -1114,8 +1154,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         constexpr int NI = 64 / RSTEP;     // 16-byte items per thread and tile
         const int q = tid & 7, n = (tid >> 3) & 1, r0 = tid >> 4;
         const int hs = tid & 1, hn = (tid >> 1) & 1, hr = tid >> 2;  // (halo items: the first 256 threads)
-        f32x4 gv[NI], xv[NI], mv[NI];
-        float md[NI], hv = 0.f;
+        typename ActT<GBF>::raw4 gv[NI], mv[NI];
+        typename ActT<XBF>::raw4 xv[NI];
+        typename ActT<XBF>::raw1 hv = 0;
+        float md[NI];
         bool ok = false, hok = false;
 
         auto issue = [&](int it) {  // loads only; consumers live in commit()
@@ -1131,17 +1173,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             }
             const int b = n ? bb[1] : bb[0], t0 = n ? tt[1] : tt[0];
             ok = n ? vv[1] : vv[0];
-            const float* gp = a.gy + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q;
-            const float* xp = a.x + ((long long)b * a.Cin + ci0 + r0) * a.T + t0 + 4 * q;
-            const float* mp = a.mask_y ? a.mask_y + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q : a.gy;
-            const float* dp = a.mask_drop ? a.mask_drop + b * a.Cout + co0 + r0 : a.gy;
+            const GT* gp = G0 + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q;
+            const XT* xp = X0 + ((long long)b * a.Cin + ci0 + r0) * a.T + t0 + 4 * q;
+            const GT* mp = a.mask_y ? M0 + ((long long)b * a.Cout + co0 + r0) * a.T + t0 + 4 * q : G0;
+            const float* dp = a.mask_drop ? a.mask_drop + b * a.Cout + co0 + r0 : a.ws;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const long long o = (long long)(RSTEP * i) * a.T;
-                gv[i] = *reinterpret_cast<const f32x4*>(gp + o);
-                xv[i] = *reinterpret_cast<const f32x4*>(xp + o);
+                gv[i] = ld_raw4(gp + o);
+                xv[i] = ld_raw4(xp + o);
                 if (a.mask_y) {  // wave-uniform
-                    mv[i] = *reinterpret_cast<const f32x4*>(mp + o);
+                    mv[i] = ld_raw4(mp + o);
                     md[i] = dp[a.mask_drop ? RSTEP * i : 0];
                 }
             }
@@ -1149,17 +1191,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                 const int hb = hn ? bb[1] : bb[0], ht0 = hn ? tt[1] : tt[0];
                 const int t = ht0 + (hs ? 32 : -1);
                 hok = (hn ? vv[1] : vv[0]) && t >= 0 && t < a.T && hr < 64;
-                hv = a.x[hok ? ((long long)hb * a.Cin + ci0 + hr) * a.T + t : 0];
+                hv = ld_raw1(X0 + (hok ? ((long long)hb * a.Cin + ci0 + hr) * a.T + t : 0));
             }
         };
         auto commit = [&](float* Gs, float* Xs) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                f32x4 g = gv[i], x = xv[i];
+                f32x4 g = widen(gv[i]), x = widen(xv[i]);
                 if (a.mask_y) {
                     const float d = a.mask_drop ? md[i] : 1.f;
+                    const f32x4 my = widen(mv[i]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] *= mv[i][e] > 0.f ? d : d * a.mask_slope;
+                    for (int e = 0; e < 4; ++e) g[e] *= my[e] > 0.f ? d : d * a.mask_slope;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1169,7 +1212,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                 *reinterpret_cast<f32x4*>(Gs + (r0 + RSTEP * i) * LD + n * SUB + 4 + 4 * q) = g;
                 *reinterpret_cast<f32x4*>(Xs + (r0 + RSTEP * i) * LD + n * SUB + 4 + 4 * q) = x;
             }
-            if (K > 1 && hr < 64) Xs[hr * LD + hn * SUB + (hs ? 36 : 3)] = hok ? hv : 0.f;
+            if (K > 1 && hr < 64) Xs[hr * LD + hn * SUB + (hs ? 36 : 3)] = hok ? widen(hv) : 0.f;
         };
 
         EEGGAN_STAMP(0, 6);
@@ -1200,18 +1243,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         float* Xs = smem + 64 * LD;  // [64][LD]
         XStage<64, NTW, LD, false> gs;
         XStage<64, NTW, LD, (K > 1)> xs;
+        const XT* const XN = nullptr;
         if (it0 < it1) {
-            gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, it0 * NTW, co0, a.vec);
-            xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, it0 * NTW, ci0, a.vec);
+            gs.load(G0, M0, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, it0 * NTW, co0, a.vec);
+            xs.load(X0, XN, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, it0 * NTW, ci0, a.vec);
         }
         for (int it = it0; it < it1; ++it) {
             gs.store(Gs);
             xs.store(Xs);
             __syncthreads();
             if (it + 1 < it1) {
-                gs.load(a.gy, a.mask_y, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, (it + 1) * NTW, co0,
-                        a.vec);
-                xs.load(a.x, nullptr, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, (it + 1) * NTW, ci0, a.vec);
+                gs.load(G0, M0, a.mask_drop, a.mask_slope, a.Cout, a.T, a.ST, a.NS, (it + 1) * NTW, co0, a.vec);
+                xs.load(X0, XN, nullptr, 0.f, a.Cin, a.T, a.ST, a.NS, (it + 1) * NTW, ci0, a.vec);
             }
             mfma_block(Gs, Xs);
             __syncthreads();
@@ -1255,9 +1298,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     }
 }
 
-template <int K, bool FULL, int SPLIT = 0>
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_kernel(WgradArgs a) {
-    wgrad_body<K, FULL, SPLIT>(a, blockIdx.x, blockIdx.y);
+    wgrad_body<K, FULL, SPLIT, XBF, GBF>(a, blockIdx.x, blockIdx.y);
 }
 
 // Several independent weight gradients in one launch: the workgroups of the grid are dealt out to the
@@ -1271,7 +1314,7 @@ struct WgradPack {
     int n;
 };
 
-template <int K, bool FULL, int SPLIT = 0>
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
@@ -1279,7 +1322,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_multi_kernel(Wgr
     const WgradArgs a = pk.j[k];
     const int local = blk - pk.first[k];
     const int region = local / a.nsplit;
-    wgrad_body<K, FULL, SPLIT>(a, local - region * a.nsplit, region);
+    wgrad_body<K, FULL, SPLIT, XBF, GBF>(a, local - region * a.nsplit, region);
 }
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
@@ -1369,7 +1412,20 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
                              int Cin, int Cout, int T, int K, float in_scale, int act, float act_param,
                              const float* act_aux, const float* mask_y, const float* mask_drop, float mask_slope,
                              void* stream) {
+    return eeggan_conv1d_t(x, w, bias, drop, y, B, Cin, Cout, T, K, in_scale, act, act_param, act_aux, mask_y, mask_drop,
+                           mask_slope, 0, 0, stream);
+}
+
+extern "C" int eeggan_conv1d_t(const void* xv, const float* w, const float* bias, const float* drop, void* yv, int B,
+                               int Cin, int Cout, int T, int K, float in_scale, int act, float act_param,
+                               const void* act_auxv, const void* mask_yv, const float* mask_drop, float mask_slope,
+                               int x_bf16, int y_bf16, void* stream) {
+    const float* x = static_cast<const float*>(xv);
+    float* y = static_cast<float*>(yv);
+    const float* act_aux = static_cast<const float*>(act_auxv);
+    const float* mask_y = static_cast<const float*>(mask_yv);
     if (check_common(B, Cin, Cout, T, K)) return 1;
+    EEGGAN_REQUIRE(!(x_bf16 || y_bf16) || T % 4 == 0, "conv1d: bfloat16 activations need T %% 4 == 0");
     EEGGAN_REQUIRE(x && w && y, "conv1d: null x/w/y pointer");
     EEGGAN_REQUIRE(act >= 0 && act <= 3, "conv1d: unknown activation code %d", act);
     EEGGAN_REQUIRE(act != EEGGAN_ACT_MASK || act_aux, "conv1d: EEGGAN_ACT_MASK needs act_aux");
@@ -1391,6 +1447,8 @@ extern "C" int eeggan_conv1d(const float* x, const float* w, const float* bias, 
     a.wpb = 0;
     a.pn_d = nullptr;
     a.pn_eps = 0.f;
+    a.x_bf16 = x_bf16 ? 1 : 0;
+    a.y_bf16 = y_bf16 ? 1 : 0;
     hipStream_t st = as_stream(stream);
     return K == 3 ? dispatch_fwd<3>(a, st) : dispatch_fwd<1>(a, st);
 }
@@ -1407,6 +1465,14 @@ extern "C" int eeggan_conv1d_pixelnorm_supported(int B, int Cin, int Cout, int T
 extern "C" int eeggan_conv1d_pixelnorm(const float* x, const float* w, const float* bias, const float* drop, float* y,
                                        float* d, int B, int Cin, int Cout, int T, int K, float in_scale, float slope,
                                        float eps, void* stream) {
+    return eeggan_conv1d_pixelnorm_t(x, w, bias, drop, y, d, B, Cin, Cout, T, K, in_scale, slope, eps, 0, stream);
+}
+
+extern "C" int eeggan_conv1d_pixelnorm_t(const void* xv, const float* w, const float* bias, const float* drop, void* yv,
+                                         float* d, int B, int Cin, int Cout, int T, int K, float in_scale, float slope,
+                                         float eps, int bf16, void* stream) {
+    const float* x = static_cast<const float*>(xv);
+    float* y = static_cast<float*>(yv);
     if (check_common(B, Cin, Cout, T, K)) return 1;
     EEGGAN_REQUIRE(x && w && y && d, "conv1d_pixelnorm: null x/w/y/d pointer");
     EEGGAN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -1420,6 +1486,9 @@ extern "C" int eeggan_conv1d_pixelnorm(const float* x, const float* w, const flo
     a.in_scale = in_scale; a.act = ACT_LRELU_PN; a.act_param = slope;
     a.vec = (T % 4 == 0) ? 1 : 0;
     a.pn_d = d; a.pn_eps = eps;
+    a.x_bf16 = a.y_bf16 = bf16 ? 1 : 0;
+    EEGGAN_REQUIRE(!bf16 || (Cin == 64 && Cout == 64 && T % 32 == 0 && product_pieces() == 1),
+                   "conv1d_pixelnorm: bfloat16 activations need a 64 -> 64 layer with T %% 32 == 0 and the bf16 matrix precision");
     EEGGAN_REQUIRE(conv_ws_covers(a, K), "conv1d_pixelnorm: shape B=%d Cin=%d Cout=%d T=%d K=%d is not covered "
                    "(see eeggan_conv1d_pixelnorm_supported)", B, Cin, Cout, T, K);
     return launch_conv_ws(a, K, as_stream(stream));
@@ -1478,6 +1547,7 @@ int launch_wgrad_partial(const char* what, const float* x, const float* gy, bool
     a.NS = B * a.ST;
     a.nci = p.nci; a.nsplit = p.nsplit; a.iters = p.iters;
     a.vec = (T % 4 == 0) ? 1 : 0;
+    a.x_bf16 = a.gy_bf16 = 0;
 #ifdef EEGGAN_TRACE
     a.trace = g_wgrad_trace;
 #endif
@@ -1666,10 +1736,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     hipStream_t st = as_stream(stream);
     constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
     const int cus = num_cus();
-    // kernel variant per job: 0 = K 3 without predicates, 1 = K 3 generic, 2 = K 1
+    // kernel variant per job: (0 = K 3 without predicates, 1 = K 3 generic, 2 = K 1) * 4 + storage types of x and gy
     auto variant = [](const eeggan_wgrad_job& j) {
         const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
-        return j.K == 3 ? (full ? 0 : 1) : 2;
+        return (j.K == 3 ? (full ? 0 : 1) : 2) * 4 + (j.x_bf16 ? 2 : 0) + (j.gy_bf16 ? 1 : 0);
     };
     for (int i = 0; i < njobs; ++i) {
         const eeggan_wgrad_job& j = jobs[i];
@@ -1679,8 +1749,14 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
         EEGGAN_REQUIRE(j.workspace && j.workspace_bytes >= p.bytes,
                        "conv1d_wgrad_partial_multi: job %d: workspace too small (%zu < %zu bytes)", i,
                        j.workspace_bytes, p.bytes);
+        const int v = variant(j);
+        // bfloat16 activations: the predicate-free k = 3 layers with both tensors bfloat16 and bf16 products, and
+        // the 1x1 layers in any combination
+        EEGGAN_REQUIRE((v & 3) == 0 || v / 4 == 2 || (v == 3 && product_pieces() == 1),
+                       "conv1d_wgrad_partial_multi: job %d: bfloat16 activations need K = 1, or K = 3 with Cin %% 64 == 0, "
+                       "Cout %% 64 == 0, T %% 32 == 0, both tensors bfloat16 and the bf16 matrix precision", i);
     }
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 12; ++v) {
         int idx[WG_MAXJ];
         int n = 0;
         auto flush = [&]() -> int {
@@ -1726,6 +1802,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 a.NS = j.B * a.ST;
                 a.nci = plan[k].nci; a.nsplit = nsplit; a.iters = (int)it;
                 a.vec = (j.T % 4 == 0) ? 1 : 0;
+                a.x_bf16 = j.x_bf16; a.gy_bf16 = j.gy_bf16;
                 pk.first[k] = first;
                 first += nsplit * plan[k].regions;
                 eeggan_reduce_job& rw = jobs_w[idx[k]];
@@ -1736,7 +1813,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 rb.scale = 1.f; rb.beta = 0.f; rb.reserved = 0;
             }
             for (int k = n; k <= WG_MAXJ; ++k) pk.first[k] = first;
-            if (v == 0) {
+            if (v / 4 == 0) {
                 // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once per device)
                 static std::atomic<bool> ready_dev[MAX_DEVICES];
                 std::atomic<bool>& ready = ready_dev[current_device()];
@@ -1749,21 +1826,32 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                     if (e == hipSuccess)
                         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                    if (e == hipSuccess)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_multi_kernel<3, true, 1, true, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                     EEGGAN_REQUIRE(e == hipSuccess, "conv1d_wgrad_partial_multi: cannot reserve LDS: %s",
                                    hipGetErrorString(e));
                     ready.store(true, std::memory_order_release);
                 }
                 const int pieces = product_pieces();
-                if (pieces == 3)
+                if (v == 3)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, true, true>), dim3(first), dim3(512), 2 * lds1, st, pk);
+                else if (pieces == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else if (pieces == 1)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true>), dim3(first), dim3(256), 2 * lds1, st, pk);
-            } else if (v == 1) {
+            } else if (v / 4 == 1) {
                 hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, false>), dim3(first), dim3(256), lds1, st, pk);
-            } else {
+            } else if (v == 8) {
                 hipLaunchKernelGGL((conv_wgrad_multi_kernel<1, false>), dim3(first), dim3(256), lds1, st, pk);
+            } else if (v == 9) {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<1, false, 0, false, true>), dim3(first), dim3(256), lds1, st, pk);
+            } else if (v == 10) {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<1, false, 0, true, false>), dim3(first), dim3(256), lds1, st, pk);
+            } else {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<1, false, 0, true, true>), dim3(first), dim3(256), lds1, st, pk);
             }
             n = 0;
             return check_launch("conv1d_wgrad_partial_multi");

@@ -19,39 +19,39 @@ struct Vec {
     float v[W];
 };
 
-template <int W>
-__device__ __forceinline__ Vec<W> load_vec(const float* p) {
+template <int W, typename T>
+__device__ __forceinline__ Vec<W> load_vec(const T* p) {
     Vec<W> r;
     if (W == 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 t = ld4(p);
 #pragma unroll
         for (int e = 0; e < W; ++e) r.v[e] = t[e];
     } else {
 #pragma unroll
-        for (int e = 0; e < W; ++e) r.v[e] = p[e];
+        for (int e = 0; e < W; ++e) r.v[e] = ld1(p + e);
     }
     return r;
 }
 
-template <int W>
-__device__ __forceinline__ void store_vec(float* p, const Vec<W>& r) {
+template <int W, typename T>
+__device__ __forceinline__ void store_vec(T* p, const Vec<W>& r) {
     if (W == 4) {
         f32x4 t;
 #pragma unroll
         for (int e = 0; e < W; ++e) t[e] = r.v[e];
-        *reinterpret_cast<f32x4*>(p) = t;
+        st4(p, t);
     } else {
 #pragma unroll
-        for (int e = 0; e < W; ++e) p[e] = r.v[e];
+        for (int e = 0; e < W; ++e) st1(p + e, r.v[e]);
     }
 }
 
 // x * (fused backward mask of the layer that produced the gradient x): see eeggan_conv1d
-template <int W>
+template <int W, typename XT>
 __device__ __forceinline__ Vec<W> load_input(const ConvArgs& a, int b, int ci, long long off) {
-    Vec<W> x = load_vec<W>(a.x + off);
+    Vec<W> x = load_vec<W>(reinterpret_cast<const XT*>(a.x) + off);
     if (a.mask_y) {  // uniform
-        const Vec<W> my = load_vec<W>(a.mask_y + off);
+        const Vec<W> my = load_vec<W>(reinterpret_cast<const XT*>(a.mask_y) + off);
         const float md = a.mask_drop ? a.mask_drop[b * a.Cin + ci] : 1.f;
 #pragma unroll
         for (int e = 0; e < W; ++e) x.v[e] *= my.v[e] > 0.f ? md : md * a.mask_slope;
@@ -59,7 +59,7 @@ __device__ __forceinline__ Vec<W> load_input(const ConvArgs& a, int b, int ci, l
     return x;
 }
 
-template <int W>
+template <int W, typename YT>
 __device__ __forceinline__ void finish(const ConvArgs& a, Vec<W> v, int b, int co, long long off) {
     const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
@@ -71,7 +71,7 @@ __device__ __forceinline__ void finish(const ConvArgs& a, Vec<W> v, int b, int c
 #pragma unroll
         for (int e = 0; e < W; ++e) v.v[e] = tanhf(v.v[e] * a.act_param);
     } else if (a.act == EEGGAN_ACT_MASK) {
-        const Vec<W> m = load_vec<W>(a.act_aux + off);
+        const Vec<W> m = load_vec<W>(reinterpret_cast<const YT*>(a.act_aux) + off);
 #pragma unroll
         for (int e = 0; e < W; ++e) v.v[e] = m.v[e] > 0.f ? v.v[e] : v.v[e] * a.act_param;
     }
@@ -80,13 +80,17 @@ __device__ __forceinline__ void finish(const ConvArgs& a, Vec<W> v, int b, int c
 #pragma unroll
         for (int e = 0; e < W; ++e) v.v[e] *= d;
     }
-    store_vec<W>(a.y + off, v);
+    store_vec<W>(reinterpret_cast<YT*>(a.y) + off, v);
 }
 
 // THIN_IN: Cin <= 8, any Cout; a thread holds its Cin inputs and walks the output channels.
 // !THIN_IN: Cout <= 8, any Cin; a thread holds its Cout sums and walks the input channels.
-template <bool THIN_IN, int W>
+// XBF / YBF: x and mask_y / y and act_aux are bfloat16 in memory (bf16 storage mode: the thin side of these layers,
+// the [B, 5, T] signals and their gradients, stays float32, so the two sides usually differ).
+template <bool THIN_IN, int W, bool XBF = false, bool YBF = false>
 __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
+    typedef typename ActT<XBF>::T XT;
+    typedef typename ActT<YBF>::T YT;
     const int TW = a.T / W;
     const long long items = (long long)a.B * TW;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
 #pragma unroll
         for (int ci = 0; ci < THIN; ++ci) {
             if (ci < a.Cin) {
-                x[ci] = load_input<W>(a, b, ci, xin + (long long)ci * a.T);
+                x[ci] = load_input<W, XT>(a, b, ci, xin + (long long)ci * a.T);
             } else {
 #pragma unroll
                 for (int e = 0; e < W; ++e) x[ci].v[e] = 0.f;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < W; ++e) s.v[e] += wv * x[ci].v[e];
             }
-            finish<W>(a, s, b, co, yout + (long long)co * a.T);
+            finish<W, YT>(a, s, b, co, yout + (long long)co * a.T);
         }
     } else {
         Vec<W> s[THIN];
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
         for (; ci + 4 <= a.Cin; ci += 4) {  // four rows in flight
             Vec<W> x[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = load_input<W>(a, b, ci + u, xin + (long long)(ci + u) * a.T);
+            for (int u = 0; u < 4; ++u) x[u] = load_input<W, XT>(a, b, ci + u, xin + (long long)(ci + u) * a.T);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
                 }
         }
         for (; ci < a.Cin; ++ci) {
-            const Vec<W> x = load_input<W>(a, b, ci, xin + (long long)ci * a.T);
+            const Vec<W> x = load_input<W, XT>(a, b, ci, xin + (long long)ci * a.T);
 #pragma unroll
             for (int co = 0; co < THIN; ++co) {
                 const float wv = co < a.Cout ? a.w[co * a.Cin + ci] : 0.f;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int co = 0; co < THIN; ++co)
-            if (co < a.Cout) finish<W>(a, s[co], b, co, yout + (long long)co * a.T);
+            if (co < a.Cout) finish<W, YT>(a, s[co], b, co, yout + (long long)co * a.T);
     }
 }
 
@@ -162,15 +166,25 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
 // (8.6 vs 15 us at 32 samples).
 int launch_conv_thin(const ConvArgs& a, int K, hipStream_t st) {
     const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool typed = a.x_bf16 || a.y_bf16;  // (the matrix-core kernel has no bfloat16 form for these layers)
     if (K != 1 || (a.Cin > THIN && a.Cout > THIN) || a.act == ACT_LRELU_PN || !a.vec || !al16(a.x) || !al16(a.y) ||
-        !al16(a.mask_y) || !al16(a.act_aux) || (long long)a.B * (a.T / 4) < 256ll * 2 * num_cus())
+        !al16(a.mask_y) || !al16(a.act_aux) || (!typed && (long long)a.B * (a.T / 4) < 256ll * 2 * num_cus()))
         return -1;
     const long long items = (long long)a.B * (a.T / 4);
     const unsigned grid = (unsigned)((items + 255) / 256);
-    if (a.Cin <= THIN)
-        hipLaunchKernelGGL((conv_thin_kernel<true, 4>), dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_thin_kernel<false, 4>), dim3(grid), dim3(256), 0, st, a);
+    const int variant = (a.Cin <= THIN ? 4 : 0) + (a.x_bf16 ? 2 : 0) + (a.y_bf16 ? 1 : 0);
+#define EEGGAN_THIN(IN, XB, YB) hipLaunchKernelGGL((conv_thin_kernel<IN, 4, XB, YB>), dim3(grid), dim3(256), 0, st, a)
+    switch (variant) {
+        case 0: EEGGAN_THIN(false, false, false); break;
+        case 1: EEGGAN_THIN(false, false, true); break;
+        case 2: EEGGAN_THIN(false, true, false); break;
+        case 3: EEGGAN_THIN(false, true, true); break;
+        case 4: EEGGAN_THIN(true, false, false); break;
+        case 5: EEGGAN_THIN(true, false, true); break;
+        case 6: EEGGAN_THIN(true, true, false); break;
+        default: EEGGAN_THIN(true, true, true); break;
+    }
+#undef EEGGAN_THIN
     return check_launch("conv1d");
 }
 

@@ -63,9 +63,17 @@ __device__ __forceinline__ void split3(float v, __bf16& p1, __bf16& p2, __bf16& 
 // SPLIT: 0 = fp32 matrix instructions; 3 = bf16 matrix instructions on three pieces per operand (fp32 products);
 // 1 = bf16 matrix instructions on the operands rounded to bf16 (the bf16 compute mode: one product instead of six,
 // no splitting; fp32 accumulation, fp32 in and out).
-template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0>
+// BF: activations (x, mask_y, y, act_aux) are bfloat16 in memory (bf16 storage mode; with SPLIT = 1 only: products
+// of fp32-exact pieces of values that carry 8 bits would be wasted work).
+template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0, bool BF = false>
 __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3), "the split form covers the 64 -> 64, k = 3 layers");
+    static_assert(!BF || SPLIT == 1, "bf16 storage runs the bf16 products");
+    typedef typename ActT<BF>::T AT;
+    typedef typename ActT<BF>::raw4 R4;
+    typedef typename ActT<BF>::raw1 R1;
+    const AT* const X0 = reinterpret_cast<const AT*>(a.x);
+    const AT* const M0 = reinterpret_cast<const AT*>(a.mask_y);
     static_assert(SPLIT == 0 || SPLIT == 1 || SPLIT == 3, "pieces per operand");
     constexpr int PAD = (K - 1) / 2;
     constexpr int KK = 64 * K;   // reduction length with the input channels padded to 64
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     const int lo = r0 * a.T + 4 * q;
     const int hlo = hr0 * a.T + (hside ? 32 : -1);
 
-    f32x4 xv[8], mv[MASKED ? 8 : 1];
-    float hv[2], mh[MASKED ? 2 : 1], md[MASKED ? 8 : 1], mdh[MASKED ? 2 : 1];
+    R4 xv[8], mv[MASKED ? 8 : 1];
+    R1 hv[2], mh[MASKED ? 2 : 1];
+    float md[MASKED ? 8 : 1], mdh[MASKED ? 2 : 1];
 
     // The waves of a workgroup take CONSECUTIVE subtiles: their 64 input rows then share pages (and
     // cache lines for the halos), which matters because every row of a unit lies in a different page.
@@ -100,8 +109,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 
     // Staging state of a unit: its base pointers and the validity of this lane's items.
     struct Unit {
-        const float* xb;
-        const float* mb;
+        const AT* xb;
+        const AT* mb;
         int b, t0, half;
         bool t_ok, h_ok;
     };
@@ -111,8 +120,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         if (RM == 1) unit >>= 1;
         r.b = unit / a.ST;
         r.t0 = (unit - r.b * a.ST) * 32;
-        r.xb = a.x + ((long long)r.b * a.Cin) * a.T + r.t0;
-        r.mb = MASKED ? a.mask_y + ((long long)r.b * a.Cin) * a.T + r.t0 : nullptr;
+        r.xb = X0 + ((long long)r.b * a.Cin) * a.T + r.t0;
+        r.mb = MASKED ? M0 + ((long long)r.b * a.Cin) * a.T + r.t0 : nullptr;
         r.t_ok = FULL || r.t0 + 4 * q < a.T;
         r.h_ok = hside ? (r.t0 + 32 < a.T) : (r.t0 > 0);
         return r;
@@ -129,9 +138,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                 const int row = hr0 + 32 * i;
                 const bool ok = un.h_ok && (FULL || row < a.Cin);
                 const int off = hlo + 32 * i * a.T;
-                hv[i] = *(ok ? un.xb + off : a.x);
+                hv[i] = ld_raw1(ok ? un.xb + off : X0);
                 if (MASKED) {
-                    mh[MASKED ? i : 0] = *(ok ? un.mb + off : a.mask_y);
+                    mh[MASKED ? i : 0] = ld_raw1(ok ? un.mb + off : M0);
                     mdh[MASKED ? i : 0] = a.mask_drop ? a.mask_drop[ok ? un.b * a.Cin + row : 0] : 1.f;
                 }
             }
@@ -142,9 +151,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
             const int row = r0 + 8 * i;
             const bool ok = FULL || (un.t_ok && row < a.Cin);
             const int off = lo + 8 * i * a.T;
-            xv[i] = *reinterpret_cast<const f32x4*>(ok ? un.xb + off : a.x);
+            xv[i] = ld_raw4(ok ? un.xb + off : X0);
             if (MASKED) {
-                mv[MASKED ? i : 0] = *reinterpret_cast<const f32x4*>(ok ? un.mb + off : a.mask_y);
+                mv[MASKED ? i : 0] = ld_raw4(ok ? un.mb + off : M0);
                 md[MASKED ? i : 0] = a.mask_drop ? a.mask_drop[ok ? un.b * a.Cin + row : 0] : 1.f;
             }
         }
@@ -156,8 +165,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = hr0 + 32 * i;
-                float v = hv[i];
-                if (MASKED) v *= mh[MASKED ? i : 0] > 0.f ? mdh[MASKED ? i : 0] : mdh[MASKED ? i : 0] * a.mask_slope;
+                float v = widen(hv[i]);
+                if (MASKED) v *= widen(mh[MASKED ? i : 0]) > 0.f ? mdh[MASKED ? i : 0] : mdh[MASKED ? i : 0] * a.mask_slope;
                 const bool ok = un.h_ok && (FULL || row < a.Cin);
                 Xs[xrow(row) + (hside ? 36 : 3)] = ok ? v : 0.f;
             }
@@ -166,9 +175,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         for (int k = 0; k < 2; ++k) {
             const int i = c + 4 * k;
             const int row = r0 + 8 * i;
-            f32x4 v = xv[i];
+            f32x4 v = widen(xv[i]);
             if (MASKED) {
-                const f32x4 my = mv[MASKED ? i : 0];
+                const f32x4 my = widen(mv[MASKED ? i : 0]);
                 const float d = md[MASKED ? i : 0];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= my[e] > 0.f ? d : d * a.mask_slope;
@@ -376,8 +385,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        float* yb = a.y + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0;
-        const float* ab = a.act_aux ? a.act_aux + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0 : a.x;
+        AT* yb = reinterpret_cast<AT*>(a.y) + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0;
+        const AT* A0 = reinterpret_cast<const AT*>(a.act_aux);
+        const AT* ab = a.act_aux ? A0 + ((long long)cur.b * a.Cout + co_base) * a.T + cur.t0 : X0;
         auto run = [&](auto tag) {
             constexpr int ACT = decltype(tag)::value;
             f32x4 m[ACT == EEGGAN_ACT_MASK ? NE : 1];
@@ -385,8 +395,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     const bool ok = st_ok && (FULL || co_base + r0 + 8 * i < a.Cout);
-                    m[ACT == EEGGAN_ACT_MASK ? i : 0] =
-                        *reinterpret_cast<const f32x4*>(ok ? ab + ylo + 8 * i * a.T : a.act_aux);
+                    m[ACT == EEGGAN_ACT_MASK ? i : 0] = ld4(ok ? ab + ylo + 8 * i * a.T : A0);
                 }
             }
             if (ACT == ACT_LRELU_PN) {
@@ -426,8 +435,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = vals[i][e] * dv[e] * drop_v;
-                    if (FULL || (st_ok && co_base + row < a.Cout))
-                        *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
+                    if (FULL || (st_ok && co_base + row < a.Cout)) st4(yb + ylo + 8 * i * a.T, v);
                 }
                 return;
             }
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
                     if (ACT == EEGGAN_ACT_MASK) t = m[ACT == EEGGAN_ACT_MASK ? i : 0][e] > 0.f ? t : t * a.act_param;
                     v[e] = t * drop_v;
                 }
-                if (FULL || (st_ok && co_base + row < a.Cout)) *reinterpret_cast<f32x4*>(yb + ylo + 8 * i * a.T) = v;
+                if (FULL || (st_ok && co_base + row < a.Cout)) st4(yb + ylo + 8 * i * a.T, v);
             }
         };
         switch (a.act) {
@@ -470,10 +478,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
     unit_body(std::false_type{}, cur);
 }
 
-template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0>
+template <int K, bool MASKED, bool FULL, int RM, int SPLIT = 0, bool BF = false>
 int launch(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)((SPLIT ? 3 * WPLANE / 4 : 64 * (64 * K + 4)) + WS_WAVES * XREG) * sizeof(float);
-    auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM, SPLIT>;
+    auto kernel = &conv_ws_kernel<K, MASKED, FULL, RM, SPLIT, BF>;
     // opt in to > 64 KiB of dynamic LDS (once per device)
     static std::atomic<bool> ready_dev[MAX_DEVICES];
     std::atomic<bool>& ready = ready_dev[current_device()];
@@ -513,6 +521,8 @@ int launch_rm(const ConvArgs& a, hipStream_t st) {
             // once for both halves of the output channels: a whole unit counts 1.3 half units, not 2 (i.e. half
             // units only while they fit one round of the chip's waves; measured +1.2 % steps/s, 1.6 the same).
             const bool halves_s = a.act != ACT_LRELU_PN && half * 10 < (whole / 2) * 13;
+            if (a.x_bf16)  // (bf16 storage: checked by the caller to come with bf16 products and a bf16 output)
+                return halves_s ? launch<K, MASKED, FULL, 1, 1, true>(a, st) : launch<K, MASKED, FULL, 2, 1, true>(a, st);
             if (pieces == 1)
                 return halves_s ? launch<K, MASKED, FULL, 1, 1>(a, st) : launch<K, MASKED, FULL, 2, 1>(a, st);
             return halves_s ? launch<K, MASKED, FULL, 1, 3>(a, st) : launch<K, MASKED, FULL, 2, 3>(a, st);
@@ -531,6 +541,10 @@ bool conv_ws_covers(const ConvArgs& a, int K) {
 int launch_conv_ws(const ConvArgs& a, int K, hipStream_t st) {
     if (!conv_ws_covers(a, K)) return -1;
     const bool full = a.Cin == 64 && a.Cout == 64 && a.T % 32 == 0;
+    if (a.x_bf16 || a.y_bf16) {
+        // bf16 storage: the 64 -> 64 layers, both sides bfloat16, bf16 products
+        if (!(a.x_bf16 && a.y_bf16 && full && product_pieces() == 1)) return -1;
+    }
     if (a.mask_y) return full ? launch_rm<3, true, true>(a, st) : launch_rm<3, true, false>(a, st);
     return full ? launch_rm<3, false, true>(a, st) : launch_rm<3, false, false>(a, st);
 }

@@ -25,9 +25,10 @@ inline unsigned blocks_stream(size_t items) {
 }
 
 // ---- leaky-relu + drop backward ------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                                             const float* __restrict__ drop, float* __restrict__ out,
+// (ET: float, or __bf16 in the bf16 storage mode: 8-byte items then; arithmetic in float either way)
+template <bool VEC, typename ET = float>
+__global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const ET* __restrict__ g, const ET* __restrict__ y,
+                                                             const float* __restrict__ drop, ET* __restrict__ out,
                                                              size_t n, int T, float slope) {
     constexpr int W = VEC ? 4 : 1;
     const size_t items = n / W;
@@ -35,14 +36,14 @@ __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __rest
         const size_t e = i * W;
         const float r = drop ? drop[e / T] : 1.f;
         if (VEC) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e);
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e);
+            const f32x4 gv = ld4(g + e);
+            const f32x4 yv = ld4(y + e);
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = gv[k] * r * (yv[k] > 0.f ? 1.f : slope);
-            *reinterpret_cast<f32x4*>(out + e) = o;
+            st4(out + e, o);
         } else {
-            out[e] = g[e] * r * (y[e] > 0.f ? 1.f : slope);
+            st1(out + e, ld1(g + e) * r * (ld1(y + e) > 0.f ? 1.f : slope));
         }
     }
 }
@@ -54,9 +55,9 @@ __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const float* __rest
 // sequential channel loop per thread.
 // CPT > 0: the channel count is CG * CPT and a thread keeps its CPT values in registers between the
 // reduction and the scaling (one read of the input instead of two; all its loads are issued up front).
-template <int W, int CG, int CPT>
-__global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restrict__ h, const float* __restrict__ drop,
-                                                            float* __restrict__ y, float* __restrict__ d, int B, int C,
+template <int W, int CG, int CPT, typename ET = float>
+__global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const ET* __restrict__ h, const float* __restrict__ drop,
+                                                            ET* __restrict__ y, float* __restrict__ d, int B, int C,
                                                             int T, float eps) {
     constexpr int UL = 256 / CG;
     __shared__ float red[CG][UL][W];
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
         if (ok) {
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
-                keep[i] = *reinterpret_cast<const f32x4*>(h + ((long long)b * C + cg + i * CG) * T + t);
+                keep[i] = ld4(h + ((long long)b * C + cg + i * CG) * T + t);
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
 #pragma unroll
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
         for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
             if (W == 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
+                const f32x4 v = ld4(h + off);
 #pragma unroll
                 for (int k = 0; k < W; ++k) s[k] += v[k] * v[k];
             } else {
-                const float v = h[off];
+                const float v = ld1(h + off);
                 s[0] += v * v;
             }
         }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < W; ++k) o[k] = keep[i][k] * dv[k] * r;
-            *reinterpret_cast<f32x4*>(y + ((long long)b * C + c) * T + t) = o;
+            st4(y + ((long long)b * C + c) * T + t, o);
         }
         return;
     }
@@ -126,21 +127,21 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const float* __restr
         const long long off = ((long long)b * C + c) * T + t;
         const float r = drop ? drop[b * C + c] : 1.f;
         if (W == 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(h + off);
+            const f32x4 v = ld4(h + off);
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < W; ++k) o[k] = v[k] * dv[k] * r;
-            *reinterpret_cast<f32x4*>(y + off) = o;
+            st4(y + off, o);
         } else {
-            y[off] = h[off] * dv[0] * r;
+            st1(y + off, ld1(h + off) * dv[0] * r);
         }
     }
 }
 
-template <int W, int CG, int CPT>
-__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+template <int W, int CG, int CPT, typename ET = float>
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const ET* __restrict__ gy, const ET* __restrict__ y,
                                                             const float* __restrict__ drop, const float* __restrict__ d,
-                                                            float* __restrict__ gc, int B, int C, int T, float slope) {
+                                                            ET* __restrict__ gc, int B, int C, int T, float slope) {
     constexpr int UL = 256 / CG;
     __shared__ float red[CG][UL][W];
     const int cg = threadIdx.x / UL, ul = threadIdx.x % UL;
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
                 const long long off = ((long long)b * C + cg + i * CG) * T + t;
-                ka[i] = *reinterpret_cast<const f32x4*>(gy + off);
-                kv[i] = *reinterpret_cast<const f32x4*>(y + off);
+                ka[i] = ld4(gy + off);
+                kv[i] = ld4(y + off);
             }
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
@@ -171,12 +172,12 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
         for (int c = cg; c < C; c += CG) {
             const long long off = ((long long)b * C + c) * T + t;
             if (W == 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
-                const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+                const f32x4 a = ld4(gy + off);
+                const f32x4 v = ld4(y + off);
 #pragma unroll
                 for (int k = 0; k < W; ++k) s[k] += a[k] * v[k];
             } else {
-                s[0] += gy[off] * y[off];
+                s[0] += ld1(gy + off) * ld1(y + off);
             }
         }
     }
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 o[k] = dv[k] * (ka[i][k] * r - kv[i][k] * ir * S[k]) * (kv[i][k] > 0.f ? 1.f : slope);
-            *reinterpret_cast<f32x4*>(gc + ((long long)b * C + c) * T + t) = o;
+            st4(gc + ((long long)b * C + c) * T + t, o);
         }
         return;
     }
@@ -212,16 +213,16 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restr
         const float r = drop ? drop[b * C + c] : 1.f;
         const float ir = 1.f / r;
         if (W == 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(gy + off);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+            const f32x4 a = ld4(gy + off);
+            const f32x4 v = ld4(y + off);
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 o[k] = dv[k] * (a[k] * r - v[k] * ir * S[k]) * (v[k] > 0.f ? 1.f : slope);
-            *reinterpret_cast<f32x4*>(gc + off) = o;
+            st4(gc + off, o);
         } else {
-            const float a = gy[off], v = y[off];
-            gc[off] = dv[0] * (a * r - v * ir * S[0]) * (v > 0.f ? 1.f : slope);
+            const float a = ld1(gy + off), v = ld1(y + off);
+            st1(gc + off, dv[0] * (a * r - v * ir * S[0]) * (v > 0.f ? 1.f : slope));
         }
     }
 }
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(256) void scaled_tanh_kernel(const float* __restric
 // out = ca*a + cb*b.  `alpha` != nullptr: the coefficients come from the fade-in factor in device
 // memory (mode 0: ca = alpha, cb = 1 - alpha; 1: ca = alpha; 2: ca = 1 - alpha) -- the same loop body as
 // the by-value form, so both give bit-identical results for equal coefficients.
-template <bool VEC, bool HASB>
-__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, float ca, const float* __restrict__ b,
-                                                    float cb, float* __restrict__ out, size_t n,
+template <bool VEC, bool HASB, typename ET = float>
+__global__ __launch_bounds__(256) void axpby_kernel(const ET* __restrict__ a, float ca, const ET* __restrict__ b,
+                                                    float cb, ET* __restrict__ out, size_t n,
                                                     const float* __restrict__ alpha, int mode) {
     constexpr int W = VEC ? 4 : 1;
     if (alpha) {
@@ -292,19 +293,19 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
     const size_t items = n / W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
         if (VEC) {
-            const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+            const f32x4 x = ld4(a + 4 * i);
             f32x4 o;
             if (HASB) {
-                const f32x4 z = reinterpret_cast<const f32x4*>(b)[i];
+                const f32x4 z = ld4(b + 4 * i);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = x[k] * ca + z[k] * cb;
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = x[k] * ca;
             }
-            reinterpret_cast<f32x4*>(out)[i] = o;
+            st4(out + 4 * i, o);
         } else {
-            out[i] = HASB ? a[i] * ca + b[i] * cb : a[i] * ca;
+            st1(out + i, HASB ? ld1(a + i) * ca + ld1(b + i) * cb : ld1(a + i) * ca);
         }
     }
 }
@@ -331,6 +332,24 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 using namespace eeggan;
 
+extern "C" int eeggan_lrelu_drop_bwd_t(const void* gv, const void* yv, const float* drop, void* outv, int B, int C,
+                                       int T, float slope, int bf16, void* stream) {
+    if (!bf16)
+        return eeggan_lrelu_drop_bwd(static_cast<const float*>(gv), static_cast<const float*>(yv), drop,
+                                     static_cast<float*>(outv), B, C, T, slope, stream);
+    const __bf16* g = static_cast<const __bf16*>(gv);
+    const __bf16* y = static_cast<const __bf16*>(yv);
+    __bf16* out = static_cast<__bf16*>(outv);
+    EEGGAN_REQUIRE(g && y && out, "lrelu_drop_bwd: null pointer");
+    EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "lrelu_drop_bwd: non-positive dimension");
+    EEGGAN_REQUIRE(T % 4 == 0 && aligned16(g) && aligned16(y) && aligned16(out),
+                   "lrelu_drop_bwd: bfloat16 tensors need T %% 4 == 0 and 16-byte alignment");
+    const size_t n = (size_t)B * C * T;
+    hipLaunchKernelGGL((lrelu_drop_bwd_kernel<true, __bf16>), dim3(blocks_stream(n / 4)), dim3(256), 0, as_stream(stream),
+                       g, y, drop, out, n, T, slope);
+    return check_launch("lrelu_drop_bwd");
+}
+
 extern "C" int eeggan_lrelu_drop_bwd(const float* g, const float* y, const float* drop, float* out, int B, int C,
                                      int T, float slope, void* stream) {
     EEGGAN_REQUIRE(g && y && out, "lrelu_drop_bwd: null pointer");
@@ -346,15 +365,20 @@ extern "C" int eeggan_lrelu_drop_bwd(const float* g, const float* y, const float
     return check_launch("lrelu_drop_bwd");
 }
 
-extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, float* y, float* d, int B, int C, int T,
-                                         float eps, void* stream) {
+template <typename ET>
+static int pixelnorm_drop_fwd_impl(const ET* h, const float* drop, ET* y, float* d, int B, int C, int T, float eps,
+                                   void* stream) {
     EEGGAN_REQUIRE(h && y && d, "pixelnorm_drop_fwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_fwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(h) && aligned16(y) && aligned16(d);
-    const PnCfg c = pn_config((long long)B * T, vec);
+    PnCfg c = pn_config((long long)B * T, vec);
+    if (sizeof(ET) == 2) {
+        EEGGAN_REQUIRE(vec, "pixelnorm_drop_fwd: bfloat16 tensors need T %% 4 == 0 and 16-byte alignment");
+        if (c.w != 4) c = {4, 16, (unsigned)(((long long)B * T / 4 + 15) / 16)};
+    }
     hipStream_t st = as_stream(stream);
 #define PN_FWD(W, CG, CPT) \
-    hipLaunchKernelGGL((pixelnorm_fwd_kernel<W, CG, CPT>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps)
+    hipLaunchKernelGGL((pixelnorm_fwd_kernel<W, CG, CPT, ET>), dim3(c.grid), dim3(256), 0, st, h, drop, y, d, B, C, T, eps)
     const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;  // channels per thread, register-resident when small
     if (c.w == 4 && c.cg == 4) {
         if (cpt == 16) PN_FWD(4, 4, 16);
@@ -366,21 +390,40 @@ extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, floa
         else if (cpt == 16) PN_FWD(4, 16, 16);
         else PN_FWD(4, 16, 0);
     } else {
-        PN_FWD(1, 16, 0);
+        if constexpr (sizeof(ET) == 4) PN_FWD(1, 16, 0);
     }
 #undef PN_FWD
     return check_launch("pixelnorm_drop_fwd");
 }
 
-extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop, const float* d, float* gc,
-                                         int B, int C, int T, float slope, void* stream) {
+extern "C" int eeggan_pixelnorm_drop_fwd(const float* h, const float* drop, float* y, float* d, int B, int C, int T,
+                                         float eps, void* stream) {
+    return pixelnorm_drop_fwd_impl<float>(h, drop, y, d, B, C, T, eps, stream);
+}
+
+extern "C" int eeggan_pixelnorm_drop_fwd_t(const void* h, const float* drop, void* y, float* d, int B, int C, int T,
+                                           float eps, int bf16, void* stream) {
+    if (bf16)
+        return pixelnorm_drop_fwd_impl<__bf16>(static_cast<const __bf16*>(h), drop, static_cast<__bf16*>(y), d, B, C, T,
+                                               eps, stream);
+    return pixelnorm_drop_fwd_impl<float>(static_cast<const float*>(h), drop, static_cast<float*>(y), d, B, C, T, eps,
+                                          stream);
+}
+
+template <typename ET>
+static int pixelnorm_drop_bwd_impl(const ET* gy, const ET* y, const float* drop, const float* d, ET* gc, int B, int C,
+                                   int T, float slope, void* stream) {
     EEGGAN_REQUIRE(gy && y && d && gc, "pixelnorm_drop_bwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_bwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
-    const PnCfg c = pn_config((long long)B * T, vec);
+    PnCfg c = pn_config((long long)B * T, vec);
+    if (sizeof(ET) == 2) {
+        EEGGAN_REQUIRE(vec, "pixelnorm_drop_bwd: bfloat16 tensors need T %% 4 == 0 and 16-byte alignment");
+        if (c.w != 4) c = {4, 16, (unsigned)(((long long)B * T / 4 + 15) / 16)};
+    }
     hipStream_t st = as_stream(stream);
 #define PN_BWD(W, CG, CPT)                                                                                     \
-    hipLaunchKernelGGL((pixelnorm_bwd_kernel<W, CG, CPT>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T, \
+    hipLaunchKernelGGL((pixelnorm_bwd_kernel<W, CG, CPT, ET>), dim3(c.grid), dim3(256), 0, st, gy, y, drop, d, gc, B, C, T, \
                        slope)
     const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;
     if (c.w == 4 && c.cg == 4) {
@@ -392,10 +435,24 @@ extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const 
         else if (cpt == 16) PN_BWD(4, 16, 16);
         else PN_BWD(4, 16, 0);
     } else {
-        PN_BWD(1, 16, 0);
+        if constexpr (sizeof(ET) == 4) PN_BWD(1, 16, 0);
     }
 #undef PN_BWD
     return check_launch("pixelnorm_drop_bwd");
+}
+
+extern "C" int eeggan_pixelnorm_drop_bwd(const float* gy, const float* y, const float* drop, const float* d, float* gc,
+                                         int B, int C, int T, float slope, void* stream) {
+    return pixelnorm_drop_bwd_impl<float>(gy, y, drop, d, gc, B, C, T, slope, stream);
+}
+
+extern "C" int eeggan_pixelnorm_drop_bwd_t(const void* gy, const void* y, const float* drop, const float* d, void* gc,
+                                           int B, int C, int T, float slope, int bf16, void* stream) {
+    if (bf16)
+        return pixelnorm_drop_bwd_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(y), drop, d,
+                                               static_cast<__bf16*>(gc), B, C, T, slope, stream);
+    return pixelnorm_drop_bwd_impl<float>(static_cast<const float*>(gy), static_cast<const float*>(y), drop, d,
+                                          static_cast<float*>(gc), B, C, T, slope, stream);
 }
 
 extern "C" int eeggan_tanh_bwd(const float* gy, const float* y, float* gc, size_t n, float scale, void* stream) {
@@ -466,6 +523,76 @@ extern "C" int eeggan_blend(const float* a, const float* b, const float* alpha, 
                                n, alpha, mode);
     }
     return check_launch("blend");
+}
+
+// bfloat16 forms of axpby / blend (bf16 storage mode: fade-in blends between layers); n % 4 == 0, 16-byte alignment
+extern "C" int eeggan_axpby_t(const void* av, float ca, const void* bv, float cb, void* outv, size_t n, int bf16,
+                              void* stream) {
+    if (!bf16)
+        return eeggan_axpby(static_cast<const float*>(av), ca, static_cast<const float*>(bv), cb, static_cast<float*>(outv),
+                            n, stream);
+    const __bf16* a = static_cast<const __bf16*>(av);
+    const __bf16* b = static_cast<const __bf16*>(bv);
+    __bf16* out = static_cast<__bf16*>(outv);
+    EEGGAN_REQUIRE(a && out && n > 0, "axpby: null pointer or empty");
+    EEGGAN_REQUIRE((n % 4 == 0) && aligned16(a) && aligned16(out) && (!b || aligned16(b)),
+                   "axpby: bfloat16 tensors need n %% 4 == 0 and 16-byte alignment");
+    hipStream_t st = as_stream(stream);
+    if (b)
+        hipLaunchKernelGGL((axpby_kernel<true, true, __bf16>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, ca, b, cb,
+                           out, n, nullptr, 0);
+    else
+        hipLaunchKernelGGL((axpby_kernel<true, false, __bf16>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, ca, b, cb,
+                           out, n, nullptr, 0);
+    return check_launch("axpby");
+}
+
+extern "C" int eeggan_blend_t(const void* av, const void* bv, const float* alpha, int mode, void* outv, size_t n,
+                              int bf16, void* stream) {
+    if (!bf16)
+        return eeggan_blend(static_cast<const float*>(av), static_cast<const float*>(bv), alpha, mode,
+                            static_cast<float*>(outv), n, stream);
+    const __bf16* a = static_cast<const __bf16*>(av);
+    const __bf16* b = static_cast<const __bf16*>(bv);
+    __bf16* out = static_cast<__bf16*>(outv);
+    EEGGAN_REQUIRE(a && alpha && out && n > 0, "blend: null pointer or empty");
+    EEGGAN_REQUIRE(mode >= 0 && mode <= 2 && (mode != 0 || b), "blend: mode %d (0 needs b)", mode);
+    if (mode != 0) b = nullptr;
+    EEGGAN_REQUIRE((n % 4 == 0) && aligned16(a) && aligned16(out) && (!b || aligned16(b)),
+                   "blend: bfloat16 tensors need n %% 4 == 0 and 16-byte alignment");
+    hipStream_t st = as_stream(stream);
+    if (b)
+        hipLaunchKernelGGL((axpby_kernel<true, true, __bf16>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, 0.f, b, 0.f,
+                           out, n, alpha, mode);
+    else
+        hipLaunchKernelGGL((axpby_kernel<true, false, __bf16>), dim3(blocks_stream(n / 4)), dim3(256), 0, st, a, 0.f, b,
+                           0.f, out, n, alpha, mode);
+    return check_launch("blend");
+}
+
+// out = in converted between float32 and bfloat16 (round to nearest even); same type on both sides: a copy
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
+    const size_t items = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256)
+        st4(out + 4 * i, ld4(in + 4 * i));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1(out + 4 * items + threadIdx.x, ld1(in + 4 * items + threadIdx.x));
+}
+
+extern "C" int eeggan_cast(const void* in, void* out, size_t n, int in_bf16, int out_bf16, void* stream) {
+    EEGGAN_REQUIRE(in && out && n > 0, "cast: null pointer or empty");
+    EEGGAN_REQUIRE(aligned16(in) && aligned16(out), "cast: tensors must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(blocks_stream(n / 4 + 1)), blk(256);
+    if (in_bf16 && out_bf16)
+        hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), grid, blk, 0, st, static_cast<const __bf16*>(in), static_cast<__bf16*>(out), n);
+    else if (in_bf16)
+        hipLaunchKernelGGL((cast_kernel<__bf16, float>), grid, blk, 0, st, static_cast<const __bf16*>(in), static_cast<float*>(out), n);
+    else if (out_bf16)
+        hipLaunchKernelGGL((cast_kernel<float, __bf16>), grid, blk, 0, st, static_cast<const float*>(in), static_cast<__bf16*>(out), n);
+    else
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, st, static_cast<const float*>(in), static_cast<float*>(out), n);
+    return check_launch("cast");
 }
 
 extern "C" int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out, int B, size_t per,

@@ -12,9 +12,10 @@ namespace {
 constexpr int RS_ROWS = 8;
 constexpr int RS_MAXTAPS = 16;
 
-template <int TAPS>
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
-                                                       const float* __restrict__ coef, float* __restrict__ out,
+// (TI / TO: float, or __bf16 for a side that is stored as bfloat16; sums in float)
+template <int TAPS, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(256) void resample_kernel(const TI* __restrict__ x, const int32_t* __restrict__ idx,
+                                                       const float* __restrict__ coef, TO* __restrict__ out,
                                                        long long rows, int Tin, int Tout) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= Tout) return;
@@ -30,11 +31,11 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     for (int r = 0; r < RS_ROWS; ++r) {
         const long long row = r0 + r;
         if (row < rows) {
-            const float* xr = x + row * Tin;
+            const TI* xr = x + row * Tin;
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < TAPS; ++k) s += cc[k] * xr[ii[k]];
-            out[row * Tout + m] = s;
+            for (int k = 0; k < TAPS; ++k) s += cc[k] * ld1(xr + ii[k]);
+            st1(out + row * Tout + m, s);
         }
     }
 }
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
 // with exact zero terms in between (the two agree up to the fusing of multiply-adds, ~1 ulp).
 constexpr int RQ_ROWS = 8;
 
-template <int NV>
-__global__ __launch_bounds__(256) void resample_quad_kernel(const float* __restrict__ x, const int32_t* __restrict__ base,
-                                                            const float* __restrict__ coef, float* __restrict__ out,
+template <int NV, typename TI = float, typename TO = float>
+__global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict__ x, const int32_t* __restrict__ base,
+                                                            const float* __restrict__ coef, TO* __restrict__ out,
                                                             long long rows, int Tin, int Tout, int chunks) {
     // threads are dealt out over (row group, quad) without regard to workgroup borders: Tout/4 is rarely a
     // multiple of 256 (320 at Tout = 1280), and a grid with one axis per row would idle the remainder
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void resample_quad_kernel(const float* __restr
     for (int r = 0; r < RQ_ROWS; ++r) {
         const long long row = r0 + r < rows ? r0 + r : rows - 1;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) xv[r][v] = *reinterpret_cast<const f32x4*>(x + row * Tin + b0 + 4 * v);
+        for (int v = 0; v < NV; ++v) xv[r][v] = ld4(x + row * Tin + b0 + 4 * v);
     }
 #pragma unroll
     for (int r = 0; r < RQ_ROWS; ++r) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void resample_quad_kernel(const float* __restr
                 for (int i = 0; i < 4; ++i) s += cf[e][v][i] * xv[r][v][i];
             o[e] = s;
         }
-        if (r0 + r < rows) *reinterpret_cast<f32x4*>(out + (r0 + r) * Tout + 4 * q) = o;
+        if (r0 + r < rows) st4(out + (r0 + r) * Tout + 4 * q, o);
     }
     }
 }
@@ -288,6 +289,12 @@ using namespace eeggan;
 
 extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float* out, size_t rows, int Tin,
                                int Tout, int taps, void* stream) {
+    return eeggan_resample_t(x, idx, coef, out, rows, Tin, Tout, taps, 0, 0, stream);
+}
+
+template <typename TI, typename TO>
+static int resample_impl(const TI* x, const int32_t* idx, const float* coef, TO* out, size_t rows, int Tin, int Tout,
+                         int taps, void* stream) {
     EEGGAN_REQUIRE(x && idx && coef && out, "resample: null pointer");
     EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample: non-positive dimension");
     EEGGAN_REQUIRE(taps >= 1 && taps <= RS_MAXTAPS, "resample: taps %d outside [1, %d]", taps, RS_MAXTAPS);
@@ -297,7 +304,7 @@ extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* 
     hipStream_t st = as_stream(stream);
 #define RS_CASE(N)                                                                                              \
     case N:                                                                                                     \
-        hipLaunchKernelGGL(resample_kernel<N>, grid, dim3(256), 0, st, x, idx, coef, out, (long long)rows, Tin, \
+        hipLaunchKernelGGL((resample_kernel<N, TI, TO>), grid, dim3(256), 0, st, x, idx, coef, out, (long long)rows, Tin, \
                            Tout);                                                                               \
         break;
     switch (taps) {
@@ -308,8 +315,24 @@ extern "C" int eeggan_resample(const float* x, const int32_t* idx, const float* 
     return check_launch("resample");
 }
 
+extern "C" int eeggan_resample_t(const void* x, const int32_t* idx, const float* coef, void* out, size_t rows, int Tin,
+                                 int Tout, int taps, int in_bf16, int out_bf16, void* stream) {
+    auto run = [&](auto* xp, auto* op) { return resample_impl(xp, idx, coef, op, rows, Tin, Tout, taps, stream); };
+    if (in_bf16)
+        return out_bf16 ? run(static_cast<const __bf16*>(x), static_cast<__bf16*>(out))
+                        : run(static_cast<const __bf16*>(x), static_cast<float*>(out));
+    return out_bf16 ? run(static_cast<const float*>(x), static_cast<__bf16*>(out))
+                    : run(static_cast<const float*>(x), static_cast<float*>(out));
+}
+
 extern "C" int eeggan_resample_quads(const float* x, const int32_t* base, const float* coef, float* out, size_t rows,
                                      int Tin, int Tout, int nv, void* stream) {
+    return eeggan_resample_quads_t(x, base, coef, out, rows, Tin, Tout, nv, 0, 0, stream);
+}
+
+template <typename TI, typename TO>
+static int resample_quads_impl(const TI* x, const int32_t* base, const float* coef, TO* out, size_t rows, int Tin,
+                               int Tout, int nv, void* stream) {
     EEGGAN_REQUIRE(x && base && coef && out, "resample_quads: null pointer");
     EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample_quads: non-positive dimension");
     EEGGAN_REQUIRE(nv >= 1 && nv <= 4, "resample_quads: nv %d outside [1, 4]", nv);
@@ -326,12 +349,22 @@ extern "C" int eeggan_resample_quads(const float* x, const int32_t* base, const 
     dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = as_stream(stream);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(resample_quad_kernel<1>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        case 2: hipLaunchKernelGGL(resample_quad_kernel<2>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        case 3: hipLaunchKernelGGL(resample_quad_kernel<3>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        default: hipLaunchKernelGGL(resample_quad_kernel<4>, grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 1: hipLaunchKernelGGL((resample_quad_kernel<1, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 2: hipLaunchKernelGGL((resample_quad_kernel<2, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 3: hipLaunchKernelGGL((resample_quad_kernel<3, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        default: hipLaunchKernelGGL((resample_quad_kernel<4, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
     }
     return check_launch("resample_quads");
+}
+
+extern "C" int eeggan_resample_quads_t(const void* x, const int32_t* base, const float* coef, void* out, size_t rows,
+                                       int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream) {
+    auto run = [&](auto* xp, auto* op) { return resample_quads_impl(xp, base, coef, op, rows, Tin, Tout, nv, stream); };
+    if (in_bf16)
+        return out_bf16 ? run(static_cast<const __bf16*>(x), static_cast<__bf16*>(out))
+                        : run(static_cast<const __bf16*>(x), static_cast<float*>(out));
+    return out_bf16 ? run(static_cast<const float*>(x), static_cast<__bf16*>(out))
+                    : run(static_cast<const float*>(x), static_cast<float*>(out));
 }
 
 extern "C" size_t eeggan_mbstd_workspace(int B, int C, int T, int group) {

@@ -48,12 +48,47 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+def _chk(t: torch.Tensor, name: str, bf16_ok: bool = False) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a HIP device tensor, got {t.device}; this package has no CPU path")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
+        raise RuntimeError(f"{name}: expected float32{' or bfloat16' if bf16_ok else ''}, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _bf(t) -> int:
+    """Storage flag of a tensor for the typed entry points (1: bfloat16)."""
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
+# Storage of the wide activations ([B, C > 8, T > 32] tensors between the conv layers, and their gradients):
+# float32 (the reference's, layers.py:150-174) or bfloat16 (the large-batch mode).  The signals themselves
+# ([B, 5, T]) and everything at the 32-sample stage (the generator's first block, the critic's last block with
+# MinibatchStddev and the full-length layer, scores, losses) stay float32, as do weights, gradients of weights
+# and optimizer state: the resampler and the 1x1 to_rgb / from_rgb layers convert on the way.
+_storage = torch.float32
+
+
+def set_storage(mode: str) -> str:
+    """'fp32' (default) or 'bf16' (which also selects the bf16 matrix precision: exact products of values that
+    carry 8 bits would be wasted work).  Process-wide, for the tensors created from now on; captured graphs keep
+    the mode they were captured in.  Returns the previous mode."""
+    global _storage
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"storage {mode!r}: expected 'fp32' or 'bf16'")
+    previous = get_storage()
+    _storage = torch.bfloat16 if mode == "bf16" else torch.float32
+    if mode == "bf16":
+        set_precision("bf16")
+    return previous
+
+
+def get_storage() -> str:
+    return "bf16" if _storage == torch.bfloat16 else "fp32"
+
+
+def _act_dtype(channels: int, length: int):
+    return _storage if (channels > 8 and length > 32) else torch.float32
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -178,7 +213,7 @@ def flipped_weights(w, cache=None):
 
 def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, act=ACT_NONE, act_param=0.0,
                act_aux=None, mask_y=None, mask_drop=None, mask_slope=0.0, flip=None, out=None):
-    x = _chk(x, "conv1d x")
+    x = _chk(x, "conv1d x", True)
     w = _chk(w, "conv1d w")
     B, Cin, T = x.shape
     K = w.shape[2]
@@ -189,37 +224,41 @@ def conv1d_raw(x, w, bias=None, drop=None, *, in_scale=1.0, transposed=False, ac
     elif w.shape[1] != Cin:
         raise RuntimeError(f"conv1d: weight {tuple(w.shape)} does not match input channels {Cin}")
     Cout = w.shape[0]
-    for name, t, shape in (("bias", bias, (Cout,)), ("drop", drop, (B, Cout)), ("act_aux", act_aux, (B, Cout, T)),
-                           ("mask_y", mask_y, (B, Cin, T)), ("mask_drop", mask_drop, (B, Cin))):
-        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32
-                              or not t.is_cuda):
-            raise RuntimeError(f"conv1d: {name} must be a contiguous float32 device tensor of shape {shape}, "
-                               f"got {tuple(t.shape)}")
+    ydt = out.dtype if out is not None else _act_dtype(Cout, T)
+    for name, t, shape, dt in (("bias", bias, (Cout,), torch.float32), ("drop", drop, (B, Cout), torch.float32),
+                               ("act_aux", act_aux, (B, Cout, T), ydt), ("mask_y", mask_y, (B, Cin, T), x.dtype),
+                               ("mask_drop", mask_drop, (B, Cin), torch.float32)):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != dt or not t.is_cuda):
+            raise RuntimeError(f"conv1d: {name} must be a contiguous {dt} device tensor of shape {shape}, "
+                               f"got {t.dtype} {tuple(t.shape)}")
     if out is None:
-        y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, Cout, T), device=x.device, dtype=ydt)
     else:
         y = out
-        if tuple(y.shape) != (B, Cout, T) or not y.is_contiguous() or y.dtype != torch.float32 or y.device != x.device:
-            raise RuntimeError(f"conv1d: out must be a contiguous float32 tensor of shape {(B, Cout, T)}")
-    call("eeggan_conv1d", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, T, K,
+        if (tuple(y.shape) != (B, Cout, T) or not y.is_contiguous() or y.device != x.device
+                or y.dtype not in (torch.float32, torch.bfloat16)):
+            raise RuntimeError(f"conv1d: out must be a contiguous float32 or bfloat16 tensor of shape {(B, Cout, T)}")
+    call("eeggan_conv1d_t", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, T, K,
          float(in_scale), int(act), float(act_param), _p(act_aux), _p(mask_y), _p(mask_drop), float(mask_slope),
-         _stream())
+         _bf(x), _bf(y), _stream())
     return y
 
 
 def conv1d_pixelnorm_raw(x, w, bias, drop, *, in_scale, slope, eps=1e-8):
     """(y, d) of the fused conv + LeakyReLU + PixelNorm + multiplier kernel, or None when the shape is
     not covered (the caller then runs the conv and the norm as two kernels)."""
-    x = _chk(x, "conv1d x")
+    x = _chk(x, "conv1d x", True)
     w = _chk(w, "conv1d w")
     B, Cin, T = x.shape
     Cout, _, K = w.shape
     if w.shape[1] != Cin or not _lib.load().eeggan_conv1d_pixelnorm_supported(B, Cin, Cout, T, K):
         return None
-    y = torch.empty((B, Cout, T), device=x.device, dtype=torch.float32)
+    if x.dtype != _act_dtype(Cout, T) or (_bf(x) and not (Cin == 64 and Cout == 64 and T % 32 == 0)):
+        return None  # (mixed storage types, or a bfloat16 shape the fused kernel has no form for: two kernels)
+    y = torch.empty((B, Cout, T), device=x.device, dtype=x.dtype)
     d = torch.empty((B, T), device=x.device, dtype=torch.float32)
-    call("eeggan_conv1d_pixelnorm", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), d.data_ptr(), B, Cin,
-         Cout, T, K, float(in_scale), float(slope), float(eps), _stream())
+    call("eeggan_conv1d_pixelnorm_t", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), d.data_ptr(), B, Cin,
+         Cout, T, K, float(in_scale), float(slope), float(eps), _bf(x), _stream())
     return y, d
 
 
@@ -227,12 +266,21 @@ def conv1d_wgrad_raw(x, gy, K, *, in_scale=1.0, need_bias=True, mask_y=None, mas
                      out_w=None, out_b=None, beta_w=0.0, beta_b=0.0):
     """Weight/bias gradient.  ``out_w``/``out_b``: write into these buffers instead of new tensors,
     as ``out = beta * out + gradient`` (beta 0: plain overwrite)."""
-    x = _chk(x, "wgrad x")
-    gy = _chk(gy, "wgrad gy")
+    x = _chk(x, "wgrad x", True)
+    gy = _chk(gy, "wgrad gy", True)
     B, Cin, T = x.shape
     if gy.shape[0] != B or gy.shape[2] != T:
         raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)} and gy {tuple(gy.shape)} disagree")
     Cout = gy.shape[1]
+    if _bf(x) or _bf(gy):
+        # bfloat16 activations: the grouped entry points have the typed kernels
+        (gw, gb), = conv1d_wgrad_group_raw([dict(x=x, gy=gy, K=K, in_scale=in_scale, need_bias=need_bias,
+                                                 mask_y=mask_y, mask_drop=mask_drop, mask_slope=mask_slope)])
+        if out_w is not None:
+            gw = axpby_raw(out_w, beta_w, gw, 1.0, out=out_w) if beta_w else out_w.copy_(gw)
+        if out_b is not None and gb is not None:
+            gb = axpby_raw(out_b, beta_b, gb, 1.0, out=out_b) if beta_b else out_b.copy_(gb)
+        return gw, gb
     for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
         if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
             raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
@@ -270,7 +318,14 @@ class _WgradJob(ctypes.Structure):
                 ("mask_drop", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
                 ("B", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int), ("T", ctypes.c_int),
                 ("K", ctypes.c_int), ("want_bias", ctypes.c_int), ("in_scale", ctypes.c_float),
-                ("mask_slope", ctypes.c_float)]
+                ("mask_slope", ctypes.c_float), ("x_bf16", ctypes.c_int), ("gy_bf16", ctypes.c_int)]
+
+
+def _wgrad_mask_check(mask_y, mask_drop, gy, B, Cout, T):
+    for name, t, shape, dt in (("mask_y", mask_y, (B, Cout, T), gy.dtype), ("mask_drop", mask_drop, (B, Cout), torch.float32)):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != dt):
+            raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous {dt} with shape {shape}, "
+                               f"got {t.dtype} {tuple(t.shape)}")
 
 
 # Weight gradients of a backward pass are submitted in groups of this many layers per launch (the
@@ -324,24 +379,22 @@ class _DirectGrads:
         return buf, beta, rnd
 
     def wgrad(self, w, bias, x, gy, in_scale, mask_y, mask_drop, slope):
-        x, gy = _chk(x, "wgrad x"), _chk(gy, "wgrad gy")
+        x, gy = _chk(x, "wgrad x", True), _chk(gy, "wgrad gy", True)
         B, Cin, T = x.shape
         Cout, K = gy.shape[1], w.shape[2]
         if gy.shape[0] != B or gy.shape[2] != T or tuple(w.shape) != (Cout, Cin, K):
             raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)}, gy {tuple(gy.shape)}, w {tuple(w.shape)} disagree")
-        for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
-            if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
-                raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
+        _wgrad_mask_check(mask_y, mask_drop, gy, B, Cout, T)
         nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         job = _WgradJob(x.data_ptr(), gy.data_ptr(), _p(mask_y), _p(mask_drop), ws.data_ptr(), nbytes, B, Cin, Cout,
-                        T, K, int(bias is not None), float(in_scale), float(slope))
+                        T, K, int(bias is not None), float(in_scale), float(slope), _bf(x), _bf(gy))
         # the tensors stay referenced until the group is submitted: nothing may recycle their memory
         # (jobs that run the same kernel variant ON THE SAME STREAM share a launch: backward nodes run on the
         # stream of their forward pass, and two critic passes may run side by side on two streams)
         stream = torch.cuda.current_stream()
         self.streams[stream.cuda_stream] = stream
-        variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0, stream.cuda_stream)
+        variant = (K, Cin % 64 == 0 and Cout % 64 == 0 and T % 32 == 0, stream.cuda_stream, _bf(x), _bf(gy))
         units = ((Cout + 63) // 64) * ((Cin + 63) // 64) * ((B * ((T + 31) // 32) + 1) // 2)
         if units >= WGRAD_SOLO_UNITS:
             variant = variant + (len(self.jobs),)  # a queue of its own, submitted right away
@@ -422,20 +475,19 @@ def conv1d_wgrad_group_raw(jobs):
     n = len(jobs)
     table, keep, outs = (_WgradJob * n)(), [], []
     for i, j in enumerate(jobs):
-        x, gy, K = _chk(j["x"], "wgrad x"), _chk(j["gy"], "wgrad gy"), int(j["K"])
+        x, gy, K = _chk(j["x"], "wgrad x", True), _chk(j["gy"], "wgrad gy", True), int(j["K"])
         B, Cin, T = x.shape
         Cout = gy.shape[1]
         if gy.shape[0] != B or gy.shape[2] != T:
             raise RuntimeError(f"conv1d_wgrad: x {tuple(x.shape)} and gy {tuple(gy.shape)} disagree")
         mask_y, mask_drop = j.get("mask_y"), j.get("mask_drop")
-        for name, t, shape in (("mask_y", mask_y, (B, Cout, T)), ("mask_drop", mask_drop, (B, Cout))):
-            if t is not None and (tuple(t.shape) != shape or not t.is_contiguous()):
-                raise RuntimeError(f"conv1d_wgrad: {name} must be contiguous with shape {shape}, got {tuple(t.shape)}")
+        _wgrad_mask_check(mask_y, mask_drop, gy, B, Cout, T)
         nbytes = _lib.load().eeggan_conv1d_wgrad_workspace(B, Cin, Cout, T, K)
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         need_bias = bool(j.get("need_bias", True))
         table[i] = _WgradJob(x.data_ptr(), gy.data_ptr(), _p(mask_y), _p(mask_drop), ws.data_ptr(), nbytes, B, Cin,
-                             Cout, T, K, int(need_bias), float(j.get("in_scale", 1.0)), float(j.get("mask_slope", 0.0)))
+                             Cout, T, K, int(need_bias), float(j.get("in_scale", 1.0)), float(j.get("mask_slope", 0.0)),
+                             _bf(x), _bf(gy))
         keep.append((x, gy, mask_y, mask_drop, ws))
         gw = torch.empty((Cout, Cin, K), device=x.device, dtype=torch.float32)
         gb = torch.empty((Cout,), device=x.device, dtype=torch.float32) if need_bias else None
@@ -481,42 +533,61 @@ def direct_weight_grads(enabled=True, deferred=False):
         _direct.enabled, _direct.deferred = prev
 
 
+def _same_dtype(what, *tensors):
+    if len({t.dtype for t in tensors}) != 1:
+        raise RuntimeError(f"{what}: tensors of different storage types {[str(t.dtype) for t in tensors]}")
+
+
 def lrelu_drop_bwd_raw(g, y, drop, slope):
-    g = _chk(g, "lrelu_drop_bwd g")
+    g = _chk(g, "lrelu_drop_bwd g", True)
+    _same_dtype("lrelu_drop_bwd", g, y)
     B, Cc, T = y.shape
     out = torch.empty_like(y)
-    call("eeggan_lrelu_drop_bwd", g.data_ptr(), y.data_ptr(), _p(drop), out.data_ptr(), B, Cc, T, float(slope),
-         _stream())
+    call("eeggan_lrelu_drop_bwd_t", g.data_ptr(), y.data_ptr(), _p(drop), out.data_ptr(), B, Cc, T, float(slope),
+         _bf(y), _stream())
     return out
 
 
 def pixelnorm_drop_fwd_raw(h, drop, eps=1e-8):
-    h = _chk(h, "pixelnorm h")
+    h = _chk(h, "pixelnorm h", True)
     B, Cc, T = h.shape
     y = torch.empty_like(h)
     d = torch.empty((B, T), device=h.device, dtype=torch.float32)
-    call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), _p(drop), y.data_ptr(), d.data_ptr(), B, Cc, T, float(eps),
-         _stream())
+    call("eeggan_pixelnorm_drop_fwd_t", h.data_ptr(), _p(drop), y.data_ptr(), d.data_ptr(), B, Cc, T, float(eps),
+         _bf(h), _stream())
     return y, d
 
 
 def pixelnorm_drop_bwd_raw(gy, y, drop, d, slope):
-    gy = _chk(gy, "pixelnorm gy")
+    gy = _chk(gy, "pixelnorm gy", True)
+    _same_dtype("pixelnorm_drop_bwd", gy, y)
     B, Cc, T = y.shape
     gc = torch.empty_like(y)
-    call("eeggan_pixelnorm_drop_bwd", gy.data_ptr(), y.data_ptr(), _p(drop), d.data_ptr(), gc.data_ptr(), B, Cc, T,
-         float(slope), _stream())
+    call("eeggan_pixelnorm_drop_bwd_t", gy.data_ptr(), y.data_ptr(), _p(drop), d.data_ptr(), gc.data_ptr(), B, Cc, T,
+         float(slope), _bf(y), _stream())
     return gc
 
 
-def axpby_raw(a, ca, b=None, cb=0.0):
-    a = _chk(a, "axpby a")
+def axpby_raw(a, ca, b=None, cb=0.0, out=None):
+    a = _chk(a, "axpby a", True)
     if b is not None:
-        b = _chk(b, "axpby b")
+        b = _chk(b, "axpby b", True)
         if b.shape != a.shape:
             raise RuntimeError(f"axpby: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
-    out = torch.empty_like(a)
-    call("eeggan_axpby", a.data_ptr(), float(ca), _p(b), float(cb), out.data_ptr(), a.numel(), _stream())
+        _same_dtype("axpby", a, b)
+    if out is None:
+        out = torch.empty_like(a)
+    elif out.shape != a.shape or out.dtype != a.dtype or not out.is_contiguous():
+        raise RuntimeError("axpby: out does not match the operands")
+    call("eeggan_axpby_t", a.data_ptr(), float(ca), _p(b), float(cb), out.data_ptr(), a.numel(), _bf(a), _stream())
+    return out
+
+
+def cast_raw(x, dtype):
+    """x converted to float32 or bfloat16 storage (round to nearest even)."""
+    x = _chk(x, "cast x", True)
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    call("eeggan_cast", x.data_ptr(), out.data_ptr(), x.numel(), _bf(x), _bf(out), _stream())
     return out
 
 
@@ -576,7 +647,7 @@ class _ConvT(Function):
     @once_differentiable
     def backward(ctx, q):
         gy, w, mask_y, mask_drop = ctx.saved_tensors
-        q = _chk(q, "ConvT cotangent")
+        q = _chk(q, "ConvT cotangent", True)
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
             if mask_y is not None:
@@ -615,7 +686,7 @@ class _Conv(Function):
         # twice-differentiated pass does not tie its backward graph to this node's own backward -- the
         # engine would otherwise run it once more on gradients that are identically zero.
         y = None if y is None else y.detach()
-        gy = _chk(gy, "conv grad")
+        gy = _chk(gy, "conv grad", True)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _ConvT.apply(gy, w, y, drop, ctx.in_scale, ctx.slope, ctx.flip)
@@ -645,7 +716,7 @@ class _MaskMul(Function):
     @staticmethod
     def backward(ctx, q):
         y, drop = ctx.saved_tensors
-        return _MaskMul.apply(_chk(q, "maskmul cotangent"), y, drop, ctx.slope), None, None, None
+        return _MaskMul.apply(_chk(q, "maskmul cotangent", True), y, drop, ctx.slope), None, None, None
 
 
 def _tail_fwd_raw(x, w, bias, drop, in_scale, act, slope):
@@ -749,7 +820,7 @@ class _GLayer(Function):
     @staticmethod
     def forward(ctx, x, w, bias, drop, in_scale, slope, mode, kind, tanh_scale, flip=None):
         ctx.flip = flip
-        x = _chk(x, "G layer x")
+        x = _chk(x, "G layer x", True)
         d = None
         if kind == "head":
             B, Cin = x.shape[0], x.shape[1]
@@ -778,7 +849,7 @@ class _GLayer(Function):
     def backward(ctx, gy):
         x, w, drop, y, d, bias = ctx.saved_tensors
         in_scale, slope, mode, kind, tanh_scale, has_bias = ctx.cfg
-        gy = _chk(gy, "G layer grad")
+        gy = _chk(gy, "G layer grad", True)
         if mode == "tanh":
             gc = torch.empty_like(y)
             call("eeggan_tanh_bwd", gy.data_ptr(), y.data_ptr(), gc.data_ptr(), y.numel(), float(tanh_scale),
@@ -866,22 +937,24 @@ USE_RESAMPLE_QUADS = os.environ.get("EEGGAN_RESAMPLE_QUADS", "1") != "0"  # (com
 
 
 def _gather_raw(x, table, out=None):
-    x = _chk(x, "resample x")
+    x = _chk(x, "resample x", True)
     idx, coef, t_in, t_out, taps, quads = table
     if x.shape[-1] != t_in:
         raise RuntimeError(f"resample: input length {x.shape[-1]} does not match the table ({t_in})")
     rows = x.numel() // t_in
     if out is None:
-        out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=torch.float32)
+        # the resampler is where the float32 tensors of the 32-sample stage meet the wide activations' storage type
+        dt = _act_dtype(x.shape[-2] if x.dim() >= 2 else 1, t_out)
+        out = torch.empty(x.shape[:-1] + (t_out,), device=x.device, dtype=dt)
     elif tuple(out.shape) != tuple(x.shape[:-1]) + (t_out,) or not out.is_contiguous():
         raise RuntimeError("resample: out does not match the result shape")
     if quads is not None and USE_RESAMPLE_QUADS and (x.data_ptr() | out.data_ptr()) % 16 == 0:
         qbase, qcoef, nv = quads  # 16-byte accesses, four outputs per thread
-        call("eeggan_resample_quads", x.data_ptr(), qbase.data_ptr(), qcoef.data_ptr(), out.data_ptr(), rows, t_in,
-             t_out, nv, _stream())
+        call("eeggan_resample_quads_t", x.data_ptr(), qbase.data_ptr(), qcoef.data_ptr(), out.data_ptr(), rows, t_in,
+             t_out, nv, _bf(x), _bf(out), _stream())
     else:
-        call("eeggan_resample", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
-             taps, _stream())
+        call("eeggan_resample_t", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
+             taps, _bf(x), _bf(out), _stream())
     return out
 
 
@@ -930,15 +1003,17 @@ def axpby(a, ca, b, cb):
 
 
 def _blend_raw(a, b, alpha, mode):
-    a = _chk(a, "blend a")
+    a = _chk(a, "blend a", True)
     if b is not None:
-        b = _chk(b, "blend b")
+        b = _chk(b, "blend b", True)
         if b.shape != a.shape:
             raise RuntimeError(f"blend: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+        _same_dtype("blend", a, b)
     if alpha.numel() != 1 or alpha.dtype != torch.float32 or alpha.device != a.device:
         raise RuntimeError("blend: alpha must be a one-element float32 tensor on the operands' device")
     out = torch.empty_like(a)
-    call("eeggan_blend", a.data_ptr(), _p(b), alpha.data_ptr(), int(mode), out.data_ptr(), a.numel(), _stream())
+    call("eeggan_blend_t", a.data_ptr(), _p(b), alpha.data_ptr(), int(mode), out.data_ptr(), a.numel(), _bf(a),
+         _stream())
     return out
 
 

@@ -126,6 +126,7 @@ typedef struct {
     void* workspace; size_t workspace_bytes;
     int B, Cin, Cout, T, K, want_bias;
     float in_scale, mask_slope;
+    int x_bf16, gy_bf16;   /* bf16 storage mode: x / gy (and mask_y) point to bfloat16 instead of float32 */
 } eeggan_wgrad_job;
 int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, int njobs,
                                       eeggan_reduce_job* jobs_w, eeggan_reduce_job* jobs_b, void* stream);
@@ -340,6 +341,49 @@ int eeggan_gru_forward(const float* gi, const float* whh, const float* bhh, floa
 size_t eeggan_feature_stats_workspace(size_t N, int F);
 int eeggan_feature_stats(const float* X, size_t N, int F, float* mean, float* cov, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* ---- bfloat16 activation storage (the large-batch mode: 512 samples per GPU) ---------------------------
+ * The reference is float32 throughout (layers.py:150-174); these forms exist for the large-batch configuration,
+ * whose 64-channel layers are bound by HBM traffic once their products run on the bf16 matrix pipe.  The `_t`
+ * ("typed") entry points are the entry points of the same name with storage flags: a flag of 1 means that the
+ * tensors it covers hold bfloat16 (2 bytes per element, round to nearest even on store) instead of float32;
+ * with all flags 0 they ARE the float32 entry points.  Arithmetic, weights, biases, multipliers (drop,
+ * mask_drop), the PixelNorm normaliser d and every reduction stay float32.
+ *   eeggan_conv1d_t           x_bf16 covers x and mask_y, y_bf16 covers y and act_aux.  bfloat16 tensors are accepted
+ *                             by the predicate-free k = 3 layers (Cin % 32 == 0, Cout % 64 == 0, T % 32 == 0; both
+ *                             flags set; matrix precision 1, eeggan_set_matrix_precision) and by 1x1 layers with at
+ *                             most 8 channels on one side (to_rgb / from_rgb and their input gradients: any
+ *                             combination of flags, T % 4 == 0); anything else fails with a message.
+ *   eeggan_conv1d_pixelnorm_t bf16 covers x and y (64 -> 64 layers, T % 32 == 0, matrix precision 1).
+ *   eeggan_wgrad_job          x_bf16 covers x, gy_bf16 covers gy and mask_y: k = 3 layers with Cin % 64 == 0,
+ *                             Cout % 64 == 0, T % 32 == 0 (both flags, matrix precision 1) and every 1x1 layer.
+ *   eeggan_resample_t / eeggan_resample_quads_t   in_bf16 / out_bf16: the two sides independently (the resampler
+ *                             is where the float32 tensors of the 32-sample stage meet the bfloat16 ones).
+ *   eeggan_lrelu_drop_bwd_t, eeggan_pixelnorm_drop_fwd_t, eeggan_pixelnorm_drop_bwd_t, eeggan_axpby_t,
+ *   eeggan_blend_t            bf16 covers every activation-shaped tensor of the call (T resp. n a multiple of 4).
+ *   eeggan_cast               out[i] = in[i] converted between the two types (equal flags: a copy). */
+int eeggan_conv1d_t(const void* x, const float* w, const float* bias, const float* drop, void* y,
+                    int B, int Cin, int Cout, int T, int K, float in_scale,
+                    int act, float act_param, const void* act_aux,
+                    const void* mask_y, const float* mask_drop, float mask_slope,
+                    int x_bf16, int y_bf16, void* stream);
+int eeggan_conv1d_pixelnorm_t(const void* x, const float* w, const float* bias, const float* drop,
+                              void* y, float* d, int B, int Cin, int Cout, int T, int K,
+                              float in_scale, float slope, float eps, int bf16, void* stream);
+int eeggan_resample_t(const void* x, const int32_t* idx, const float* coef, void* out,
+                      size_t rows, int Tin, int Tout, int taps, int in_bf16, int out_bf16, void* stream);
+int eeggan_resample_quads_t(const void* x, const int32_t* base, const float* coef, void* out,
+                            size_t rows, int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream);
+int eeggan_lrelu_drop_bwd_t(const void* g, const void* y, const float* drop, void* out,
+                            int B, int C, int T, float slope, int bf16, void* stream);
+int eeggan_pixelnorm_drop_fwd_t(const void* h, const float* drop, void* y, float* d,
+                                int B, int C, int T, float eps, int bf16, void* stream);
+int eeggan_pixelnorm_drop_bwd_t(const void* gy, const void* y, const float* drop, const float* d,
+                                void* gc, int B, int C, int T, float slope, int bf16, void* stream);
+int eeggan_axpby_t(const void* a, float ca, const void* b, float cb, void* out, size_t n, int bf16, void* stream);
+int eeggan_blend_t(const void* a, const void* b, const float* alpha, int mode, void* out, size_t n, int bf16,
+                   void* stream);
+int eeggan_cast(const void* in, void* out, size_t n, int in_bf16, int out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,12 @@ def test_default_mode_is_untouched(dev):
 
 @pytest.mark.parametrize("name", ["e2e_d4_a1", "e2e_d7_a1", "e2e_d7_a05"])
 def test_stated_bounds_against_reference_fixture(dev, bf16_mode, name):
+    run_bounds(dev, name, "bf16 mode", FWD_BOUND, SUMMED_BOUND, GRAD_BOUND)
+
+
+def run_bounds(dev, name, label, FWD_BOUND, SUMMED_BOUND, GRAD_BOUND):
+    """One critic and one generator iteration on a reference fixture in the mode that is in force, held to the
+    given bounds against the reference's fp64 run (also used for the bf16 storage mode)."""
     from eeggan_amd import config, layers, losses, ops
     import test_e2e_gpu as E
     fx = load_fixture(name)
@@ -144,7 +150,7 @@ def test_stated_bounds_against_reference_fixture(dev, bf16_mode, name):
         e = rel(subsample(p.grad), fx[f"g_grads_sub.{k}"])
         worst["g"] = max(worst["g"], e)
         worst_of["generator"] = max(worst_of.get("generator", (0.0, "")), (e, k))
-    print(f"{name} bf16 mode, worst deviations from the reference's fp64 run: forward {worst['fwd']:.2e}; " +
+    print(f"{name} {label}, worst deviations from the reference's fp64 run: forward {worst['fwd']:.2e}; " +
           "; ".join(f"{grp} {e:.2e} ({k})" for grp, (e, k) in worst_of.items()))
     for grp, (e, k) in worst_of.items():
         assert e < (SUMMED_BOUND if grp == "critic, summed" else GRAD_BOUND), f"{grp}, {k}: {e:.3e}"
