@@ -16,7 +16,8 @@ from typing import Optional
 import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeeggan_hip.so")
+# (EEGGAN_LIB: another build of the same library, for same-session comparisons of two builds)
+LIB_PATH = os.environ.get("EEGGAN_LIB") or os.path.join(_HERE, "libeeggan_hip.so")
 
 _f = C.c_void_p      # device float*
 _i = C.c_int

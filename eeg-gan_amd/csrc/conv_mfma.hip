@@ -30,6 +30,22 @@ constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment
 // Split products: an fp32 operand as the sum of three bf16 pieces (v = p1 + p2 + p3 up to 2^-24 |v|), see conv_ws.hip
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+// Two values at once (see conv_ws.hip: the packed conversion's result is the operand word)
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16s(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3s_pair(float a, float b, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = pack_bf16s(a, b);
+    const float ra = a - __builtin_bit_cast(float, w1 << 16), rb = b - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = pack_bf16s(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w2 << 16), sb = rb - __builtin_bit_cast(float, w2 & 0xffff0000u);
+    w3 = pack_bf16s(sa, sb);
+}
 __device__ __forceinline__ void split3s(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)v;
     const float r1 = v - (float)p1;
@@ -437,17 +453,22 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         float* Xs = buf + CT * WLD;
         if constexpr (FULL) {
             if constexpr (SPLIT) {
-                bf16x4s p[3][3];  // [tap][piece]: this thread's channels 4 (tid & 7) .. + 3 of the chunk
+                u32x2s p[3][3];  // [tap][piece]: this thread's channels 4 (tid & 7) .. + 3 of the chunk, two per word
 #pragma unroll
-                for (int i = 0; i < WV; ++i)
+                for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 4 * i + e, c = k / 3, tap = k - 3 * c;
-                        __bf16 p1, p2, p3;
-                        split3s(wv[i][e] * a.in_scale, p1, p2, p3);
-                        p[tap][0][c] = p1;
-                        p[tap][1][c] = p2;
-                        p[tap][2][c] = p3;
+                    for (int cp = 0; cp < 2; ++cp) {
+                        const int k0 = 6 * cp + tap, k1 = k0 + 3;  // float k of the thread is tap k % 3 of channel k / 3
+                        unsigned w1, w2, w3;
+                        if constexpr (SPLIT == 3) {
+                            split3s_pair(wv[k0 / 4][k0 % 4] * a.in_scale, wv[k1 / 4][k1 % 4] * a.in_scale, w1, w2, w3);
+                        } else {
+                            w1 = pack_bf16s(wv[k0 / 4][k0 % 4] * a.in_scale, wv[k1 / 4][k1 % 4] * a.in_scale);
+                            w2 = w3 = 0;
+                        }
+                        p[tap][0][cp] = w1;
+                        p[tap][1][cp] = w2;
+                        p[tap][2][cp] = w3;
                     }
                 const int g4 = tid & 7;  // channels 4 g4 ..: k-step half g4 >> 2, lane half (g4 >> 1) & 1, fragment half g4 & 1
                 char* Wb = reinterpret_cast<char*>(Ws) + (tid >> 3) * WROWB + (g4 >> 2) * 32 + ((g4 >> 1) & 1) * 16 + (g4 & 1) * 8;
@@ -455,7 +476,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
-                        *reinterpret_cast<bf16x4s*>(Wb + k * CT * WROWB + tap * 64) = p[tap][k];
+                        *reinterpret_cast<u32x2s*>(Wb + k * CT * WROWB + tap * 64) = p[tap][k];
             } else {
 #pragma unroll
                 for (int i = 0; i < WV; ++i) {
@@ -633,15 +654,17 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][0], acc[i][n], 0, 0, 0);
                         continue;
                     }
-                    bf16x8s x1, x2, x3;
+                    u32x4s q1, q2, q3;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        __bf16 p1, p2, p3;
-                        split3s(xr[u][n][i], p1, p2, p3);
-                        x1[i] = p1;
-                        x2[i] = p2;
-                        x3[i] = p3;
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned w1_, w2_, w3_;
+                        split3s_pair(xr[u][n][2 * i], xr[u][n][2 * i + 1], w1_, w2_, w3_);
+                        q1[i] = w1_;
+                        q2[i] = w2_;
+                        q3[i] = w3_;
                     }
+                    const bf16x8s x1 = __builtin_bit_cast(bf16x8s, q1), x2 = __builtin_bit_cast(bf16x8s, q2),
+                                  x3 = __builtin_bit_cast(bf16x8s, q3);
 #pragma unroll
                     for (int i = 0; i < RM; ++i) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1[i][0], acc[i][n], 0, 0, 0);
@@ -1088,27 +1111,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                         }
                         continue;
                     }
-                    bf16x8s G1, G2, G3;
+                    // pieces two values per word (the packed conversion's result is the operand word)
+                    u32x4s gw1, gw2, gw3;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        __bf16 p1, p2, p3;
-                        split3s(i < 4 ? g0[i] : g1[i - 4], p1, p2, p3);
-                        G1[i] = p1;
-                        G2[i] = p2;
-                        G3[i] = p3;
+                    for (int i = 0; i < 4; ++i) {
+                        unsigned w1_, w2_, w3_;
+                        split3s_pair(i < 2 ? g0[2 * i] : g1[2 * i - 4], i < 2 ? g0[2 * i + 1] : g1[2 * i - 3], w1_, w2_, w3_);
+                        gw1[i] = w1_;
+                        gw2[i] = w2_;
+                        gw3[i] = w3_;
                     }
-                    __bf16 q1[10], q2[10], q3[10];
+                    const bf16x8s G1 = __builtin_bit_cast(bf16x8s, gw1), G2 = __builtin_bit_cast(bf16x8s, gw2),
+                                  G3 = __builtin_bit_cast(bf16x8s, gw3);
+                    unsigned qw[3][5];  // [piece][word]: samples 2 w, 2 w + 1 of the ten around the lane's eight
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) split3s(xs[i], q1[i], q2[i], q3[i]);
+                    for (int i = 0; i < 5; ++i) split3s_pair(xs[2 * i], xs[2 * i + 1], qw[0][i], qw[1][i], qw[2][i]);
 #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        bf16x8s X1, X2, X3;
+                        // tap j reads samples j .. j + 7: whole words for even j, words re-cut across their borders for odd j
+                        u32x4s xw[3];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            X1[i] = q1[i + j];
-                            X2[i] = q2[i + j];
-                            X3[i] = q3[i + j];
-                        }
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                xw[k][i] = (j & 1) ? __builtin_amdgcn_alignbit(qw[k][i + (j >> 1) + 1], qw[k][i + (j >> 1)], 16)
+                                                   : qw[k][i + (j >> 1)];
+                        const bf16x8s X1 = __builtin_bit_cast(bf16x8s, xw[0]), X2 = __builtin_bit_cast(bf16x8s, xw[1]),
+                                      X3 = __builtin_bit_cast(bf16x8s, xw[2]);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G3, X1, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X3, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G2, X2, acc[j], 0, 0, 0);

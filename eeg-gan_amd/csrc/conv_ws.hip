@@ -43,9 +43,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int WROWB = 400;           // bytes per output channel and piece: 8 groups x 3 taps x 8 channels x 2 B, + 16
 constexpr int WPLANE = 64 * WROWB;   // bytes per piece
 
-struct Split3 {
-    bf16x8 p1, p2, p3;
-};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Two values at once: the packed conversion (v_cvt_pk_bf16_f32) writes both pieces into one register, which is
+// already the operand word; the pieces' float values for the remainders come out of it with a shift and a mask.
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& w1, unsigned& w2, unsigned& w3) {
+    w1 = pack_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, w1 << 16), rb = b - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = pack_bf16(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w2 << 16), sb = rb - __builtin_bit_cast(float, w2 & 0xffff0000u);
+    w3 = pack_bf16(sa, sb);
+}
 __device__ __forceinline__ void split3(float v, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)v;
     const float r1 = v - (float)p1;
@@ -226,22 +239,23 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
         // piece planes, [co][lane half h][chunk c][tap][8 channels]: the 8 channels 32h + 8c + i of one tap are one
         // 16-byte operand fragment; this thread's group is (h, c) = (group >> 2, group & 3), i.e. slot `group`
         char* Wb = reinterpret_cast<char*>(smem) + (tid >> 3) * WROWB + (tid & 7) * 3 * 16;
-        bf16x8 p[3][3];  // [tap][piece]
+        u32x4 p[3][3];  // [tap][piece]: four words of two channels each
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = 4 * i + e, ci = k / 3, tap = k - 3 * ci;  // this thread's float k: channel ci of its group
-                __bf16 p1, p2, p3;
-                split3(wv[FULL ? i : 0][e] * a.in_scale, p1, p2, p3);
-                p[tap][0][ci] = p1;
-                p[tap][1][ci] = p2;
-                p[tap][2][ci] = p3;
+            for (int cp = 0; cp < 4; ++cp) {
+                // this thread's float k is tap k % 3 of channel k / 3 of its group: channels 2 cp and 2 cp + 1
+                const int k0 = 6 * cp + tap, k1 = k0 + 3;
+                unsigned w1, w2, w3;
+                split3_pair(wv[FULL ? k0 / 4 : 0][k0 % 4] * a.in_scale, wv[FULL ? k1 / 4 : 0][k1 % 4] * a.in_scale, w1, w2, w3);
+                p[tap][0][cp] = w1;
+                p[tap][1][cp] = w2;
+                p[tap][2][cp] = w3;
             }
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(Wb + k * WPLANE + tap * 16) = p[tap][k];
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(Wb + k * WPLANE + tap * 16) = p[tap][k];
     } else if (FULL) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
@@ -302,6 +316,102 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
         const float* Au = Ap + co_base * WLD;
+        if constexpr (SPLIT == 3) {
+            // Twelve steps (chunk c, tap j) of two half steps (one 32-channel output tile: 6 MFMAs) each, software-
+            // pipelined so that every MFMA gap carries its share of the other work.  A SIMD issues one vector
+            // instruction at a time, and an MFMA holds that issue port for 8 of its 32 cycles: the ~50 VALU
+            // instructions that split a step's 8 input samples are free while they sit BETWEEN the MFMAs of the same
+            // wave (4-5 per gap), and cost their full issue time in a block of their own -- the partner wave on the
+            // SIMD cannot fill such a block with its MFMAs, the older wave's VALU stream takes every issue slot.
+            //   during half step (s, tile):  LDS reads of the weight fragments of the next half step (and, on tile 0,
+            //   of the input samples of step s + 2), the splitting of half of step s + 1's samples, 6 MFMAs of step s.
+            // Chunk c + 1 is committed to LDS at the top of step 3c + 1, before the first reads of its samples (a
+            // wave's LDS operations execute in order: its reads see its own writes).
+            const char* Wl = reinterpret_cast<const char*>(smem) + (co_base + l31) * WROWB + (h * 4) * 3 * 16;
+            float xa[8], xb[8];        // raw samples of steps s + 1 / s + 2 (alternating)
+            bf16x8 wc[3], wn[3];       // weight fragments (three piece planes) of this / the next half step
+            u32x4 pc[3], pn[3];        // piece vectors of this / the next step's samples (8 bf16 each)
+            auto read_x = [&](int st, float (&xr)[8]) {
+                const int c = st / 3, j = st - 3 * c;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xr[i] = Bp[(8 * c + i) * XL + j];
+            };
+            auto read_w = [&](int st, int tile, bf16x8 (&wr)[3]) {
+                const int c = st / 3, j = st - 3 * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    wr[k] = *reinterpret_cast<const bf16x8*>(Wl + c * 3 * 16 + tile * 32 * WROWB + j * 16 + k * WPLANE);
+            };
+            auto split_half = [&](const float (&xr)[8], int half, u32x4 (&p)[3]) {
+#pragma unroll
+                for (int i = 2 * half; i < 2 * half + 2; ++i) {
+                    unsigned w1, w2, w3;
+                    split3_pair(xr[2 * i], xr[2 * i + 1], w1, w2, w3);
+                    p[0][i] = w1;
+                    p[1][i] = w2;
+                    p[2][i] = w3;
+                }
+            };
+            commit_chunk(cur, 0);
+            if (MORE) issue_chunk(nxt, 0);
+            read_x(0, xb);
+            read_x(1, xa);
+            read_w(0, 0, wc);
+            split_half(xb, 0, pc);
+            split_half(xb, 1, pc);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                if (st % 3 == 1 && st < 10) {
+                    commit_chunk(cur, st / 3 + 1);
+                    if (MORE) issue_chunk(nxt, st / 3 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float(&xnext)[8] = (st & 1) ? xb : xa;   // samples of step st + 1 (read during step st - 1)
+                float(&xfar)[8] = (st & 1) ? xa : xb;    // buffer the samples of step st + 2 go to
+#pragma unroll
+                for (int tile = 0; tile < RM; ++tile) {
+                    int nreads = 0;
+                    if (tile + 1 < RM) {
+                        read_w(st, tile + 1, wn);
+                        nreads += 3;
+                    } else if (st < 11) {
+                        read_w(st + 1, 0, wn);
+                        nreads += 3;
+                    }
+                    if (st < 11) split_half(xnext, RM == 2 ? tile : 0, pn);
+                    if (RM == 1 && st < 11) split_half(xnext, 1, pn);
+                    if (tile == RM - 1 && st < 10) {
+                        // (after the splitting in program order: the buffer that held step st + 1's samples on the
+                        // previous step is xfar only on the NEXT step, this one is free since step st - 1)
+                        read_x(st + 2, xfar);
+                        nreads += 4;
+                    }
+                    f32x16& acc = tile == 0 ? acc0 : acc1;
+                    const bf16x8 x1 = __builtin_bit_cast(bf16x8, pc[0]), x2 = __builtin_bit_cast(bf16x8, pc[1]),
+                                 x3 = __builtin_bit_cast(bf16x8, pc[2]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, wc[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, wc[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, wc[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, wc[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, wc[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, wc[0], acc, 0, 0, 0);
+                    // order inside the half step: the reads, then MFMA / VALU alternating
+                    __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#pragma unroll
+                    for (int g = 0; g < 6; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, RM == 2 ? 4 : 8, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    (void)nreads;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wc[k] = wn[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pc[k] = pn[k];
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             commit_chunk(cur, c);

@@ -28,6 +28,17 @@ int main(int argc, char** argv) {
     a.trace = nullptr;
     for (int i = 0; i < 5; ++i) dispatch_fwd<3>(a, 0);
     hipDeviceSynchronize();
+    {   // un-traced launches back to back: the kernel's duration as the bench line reports it
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 50; ++i) dispatch_fwd<3>(a, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("back to back: %.2f us per launch\n", ms * 1000.f / 50);
+    }
     hipMemset(tr, 0, ntr * 8);
     a.trace = tr;
     dispatch_fwd<3>(a, 0);
