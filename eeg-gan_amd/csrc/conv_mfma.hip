@@ -639,32 +639,49 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                 if (HOISTW) read_w(u, s);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
 #pragma unroll
-            for (int u = 0; u < NSTEP; ++u) {
-                if (!HOISTW) read_w(u, kid * NSTEP + u);
-                const bf16x8s(&w1)[RM][3] = wf[HOISTW ? u : 0];
+                for (int u = 0; u < NSTEP; ++u) {
+                    if (!HOISTW) read_w(u, kid * NSTEP + u);
+                    const bf16x8s(&w1)[RM][3] = wf[HOISTW ? u : 0];
 #pragma unroll
-                for (int n = 0; n < RN; ++n) {
-                    if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
-                        bf16x8s x1;
+                    for (int n = 0; n < RN; ++n) {
+                        u32x4s q1;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) x1[i] = (__bf16)xr[u][n][i];
+                        for (int i = 0; i < 4; ++i) q1[i] = pack_bf16s(xr[u][n][2 * i], xr[u][n][2 * i + 1]);
+                        const bf16x8s x1 = __builtin_bit_cast(bf16x8s, q1);
 #pragma unroll
                         for (int i = 0; i < RM; ++i)
                             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][0], acc[i][n], 0, 0, 0);
-                        continue;
                     }
-                    u32x4s q1, q2, q3;
+                }
+            } else {
+                // items (k-step u, subtile n): 8 samples split into pieces (VALU), then 6 MFMAs per row tile.  The
+                // splitting of item it + 1 is placed in the MFMA gaps of item it: a vector instruction between two MFMAs
+                // of the same wave is free, a block of them ahead of the MFMAs costs its full issue time (conv_ws.hip).
+                constexpr int NITEM = NSTEP * RN;
+                u32x4s qc[3], qn[3];
+                auto prep = [&](int it, u32x4s (&q)[3]) {
+                    const int u = it / RN, n = it - u * RN;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         unsigned w1_, w2_, w3_;
                         split3s_pair(xr[u][n][2 * i], xr[u][n][2 * i + 1], w1_, w2_, w3_);
-                        q1[i] = w1_;
-                        q2[i] = w2_;
-                        q3[i] = w3_;
+                        q[0][i] = w1_;
+                        q[1][i] = w2_;
+                        q[2][i] = w3_;
                     }
-                    const bf16x8s x1 = __builtin_bit_cast(bf16x8s, q1), x2 = __builtin_bit_cast(bf16x8s, q2),
-                                  x3 = __builtin_bit_cast(bf16x8s, q3);
+                };
+                prep(0, qc);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < NITEM; ++it) {
+                    const int u = it / RN, n = it - u * RN;
+                    if (!HOISTW && n == 0) read_w(u, kid * NSTEP + u);
+                    const bf16x8s(&w1)[RM][3] = wf[HOISTW ? u : 0];
+                    if (it + 1 < NITEM) prep(it + 1, qn);
+                    const bf16x8s x1 = __builtin_bit_cast(bf16x8s, qc[0]), x2 = __builtin_bit_cast(bf16x8s, qc[1]),
+                                  x3 = __builtin_bit_cast(bf16x8s, qc[2]);
 #pragma unroll
                     for (int i = 0; i < RM; ++i) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, w1[i][0], acc[i][n], 0, 0, 0);
@@ -674,6 +691,15 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][1], acc[i][n], 0, 0, 0);
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, w1[i][0], acc[i][n], 0, 0, 0);
                     }
+                    if (!HOISTW && n == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3 * RM, 0);
+#pragma unroll
+                    for (int g = 0; g < 6 * RM; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, RM == 1 ? 8 : 4, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) qc[k] = qn[k];
                 }
             }
         } else
@@ -1081,63 +1107,79 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
 
     auto mfma_block = [&](const float* Gs, const float* Xs) {
         if constexpr (SPLIT) {
-            const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h;
-            const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h;
-            {
-                const int n = part;  // this wave's subtile of the pair
+            const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h + part * SUB;  // (this wave's subtile of the pair)
+            const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h + part * SUB;
+            // Two halves of 16 time steps; per half this lane's 8 time steps of the gradient row and the 10 input
+            // samples around them.  All LDS reads first; the operands of the second half are prepared (VALU) in the
+            // MFMA gaps of the first half -- a vector instruction between two MFMAs of the same wave is free, a block
+            // of them ahead of the MFMAs is not (see conv_ws.hip).
+            f32x4 g0[2], g1[2], x0[2], x1[2];
+            float xl[2], xh[2];
 #pragma unroll
-                for (int tb = 0; tb < 32; tb += 16) {
-                    // this lane's 8 time steps tb + 8h .. +7 of the gradient row, and the 10 input samples around them
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gr + n * SUB + tb);
-                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(Gr + n * SUB + tb + 4);
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(Xr + n * SUB + tb);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(Xr + n * SUB + tb + 4);
-                    const float xs[10] = {Xr[n * SUB + tb - 1], x0[0], x0[1], x0[2], x0[3],
-                                          x1[0], x1[1], x1[2], x1[3], Xr[n * SUB + tb + 8]};
-                    if (do_bias) bsum += ((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]));
-                    if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
-                        bf16x8s G1;
-                        __bf16 q1[10];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int tb = 16 * hf;
+                g0[hf] = *reinterpret_cast<const f32x4*>(Gr + tb);
+                g1[hf] = *reinterpret_cast<const f32x4*>(Gr + tb + 4);
+                x0[hf] = *reinterpret_cast<const f32x4*>(Xr + tb);
+                x1[hf] = *reinterpret_cast<const f32x4*>(Xr + tb + 4);
+                xl[hf] = Xr[tb - 1];
+                xh[hf] = Xr[tb + 8];
+            }
+            // operand words of one half: G pieces [piece] (8 values), X pieces [tap][piece] (8 values each)
+            struct Ops {
+                u32x4s g[3], x[K][3];
+            };
+            auto prepare = [&](int hf, Ops& o) {
+                const float gs[8] = {g0[hf][0], g0[hf][1], g0[hf][2], g0[hf][3], g1[hf][0], g1[hf][1], g1[hf][2], g1[hf][3]};
+                const float xs[10] = {xl[hf], x0[hf][0], x0[hf][1], x0[hf][2], x0[hf][3],
+                                      x1[hf][0], x1[hf][1], x1[hf][2], x1[hf][3], xh[hf]};
+                if (do_bias) bsum += ((gs[0] + gs[1]) + (gs[2] + gs[3])) + ((gs[4] + gs[5]) + (gs[6] + gs[7]));
+                if constexpr (SPLIT == 1) {  // bf16 compute mode: the operands rounded to bf16, one product
+                    unsigned qw[5];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) G1[i] = (__bf16)(i < 4 ? g0[i] : g1[i - 4]);
+                    for (int i = 0; i < 4; ++i) o.g[0][i] = pack_bf16s(gs[2 * i], gs[2 * i + 1]);
 #pragma unroll
-                        for (int i = 0; i < 10; ++i) q1[i] = (__bf16)xs[i];
+                    for (int i = 0; i < 5; ++i) qw[i] = pack_bf16s(xs[2 * i], xs[2 * i + 1]);
 #pragma unroll
-                        for (int j = 0; j < K; ++j) {
-                            bf16x8s X1;
+                    for (int j = 0; j < K; ++j)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) X1[i] = q1[i + j];
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X1, acc[j], 0, 0, 0);
-                        }
-                        continue;
-                    }
-                    // pieces two values per word (the packed conversion's result is the operand word)
-                    u32x4s gw1, gw2, gw3;
+                        for (int i = 0; i < 4; ++i)
+                            o.x[j][0][i] = (j & 1) ? __builtin_amdgcn_alignbit(qw[i + (j >> 1) + 1], qw[i + (j >> 1)], 16)
+                                                   : qw[i + (j >> 1)];
+                    return;
+                }
+                // pieces two values per word (the packed conversion's result is the operand word)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        unsigned w1_, w2_, w3_;
-                        split3s_pair(i < 2 ? g0[2 * i] : g1[2 * i - 4], i < 2 ? g0[2 * i + 1] : g1[2 * i - 3], w1_, w2_, w3_);
-                        gw1[i] = w1_;
-                        gw2[i] = w2_;
-                        gw3[i] = w3_;
-                    }
-                    const bf16x8s G1 = __builtin_bit_cast(bf16x8s, gw1), G2 = __builtin_bit_cast(bf16x8s, gw2),
-                                  G3 = __builtin_bit_cast(bf16x8s, gw3);
-                    unsigned qw[3][5];  // [piece][word]: samples 2 w, 2 w + 1 of the ten around the lane's eight
+                for (int i = 0; i < 4; ++i) {
+                    unsigned w1_, w2_, w3_;
+                    split3s_pair(gs[2 * i], gs[2 * i + 1], w1_, w2_, w3_);
+                    o.g[0][i] = w1_;
+                    o.g[1][i] = w2_;
+                    o.g[2][i] = w3_;
+                }
+                unsigned qw[3][5];  // [piece][word]: samples 2 w, 2 w + 1 of the ten
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) split3s_pair(xs[2 * i], xs[2 * i + 1], qw[0][i], qw[1][i], qw[2][i]);
+                for (int i = 0; i < 5; ++i) split3s_pair(xs[2 * i], xs[2 * i + 1], qw[0][i], qw[1][i], qw[2][i]);
+                // tap j reads samples j .. j + 7: whole words for even j, words re-cut across their borders for odd j
 #pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        // tap j reads samples j .. j + 7: whole words for even j, words re-cut across their borders for odd j
-                        u32x4s xw[3];
+                for (int j = 0; j < K; ++j)
 #pragma unroll
-                        for (int k = 0; k < 3; ++k)
+                    for (int k = 0; k < 3; ++k)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                xw[k][i] = (j & 1) ? __builtin_amdgcn_alignbit(qw[k][i + (j >> 1) + 1], qw[k][i + (j >> 1)], 16)
+                        for (int i = 0; i < 4; ++i)
+                            o.x[j][k][i] = (j & 1) ? __builtin_amdgcn_alignbit(qw[k][i + (j >> 1) + 1], qw[k][i + (j >> 1)], 16)
                                                    : qw[k][i + (j >> 1)];
-                        const bf16x8s X1 = __builtin_bit_cast(bf16x8s, xw[0]), X2 = __builtin_bit_cast(bf16x8s, xw[1]),
-                                      X3 = __builtin_bit_cast(bf16x8s, xw[2]);
+            };
+            auto multiply = [&](const Ops& o) {
+                const bf16x8s G1 = __builtin_bit_cast(bf16x8s, o.g[0]);
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bf16x8s X1 = __builtin_bit_cast(bf16x8s, o.x[j][0]);
+                    if constexpr (SPLIT == 1) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X1, acc[j], 0, 0, 0);
+                    } else {
+                        const bf16x8s G2 = __builtin_bit_cast(bf16x8s, o.g[1]), G3 = __builtin_bit_cast(bf16x8s, o.g[2]);
+                        const bf16x8s X2 = __builtin_bit_cast(bf16x8s, o.x[j][1]), X3 = __builtin_bit_cast(bf16x8s, o.x[j][2]);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G3, X1, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X3, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G2, X2, acc[j], 0, 0, 0);
@@ -1146,7 +1188,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, X1, acc[j], 0, 0, 0);
                     }
                 }
+            };
+            Ops oa, ob;
+            prepare(0, oa);
+            __builtin_amdgcn_sched_barrier(0);
+            prepare(1, ob);
+            multiply(oa);
+            if constexpr (SPLIT == 3) {
+#pragma unroll
+                for (int g = 0; g < 6 * K; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(ob);
             return;
         }
         const float* Gp = Gs + (cot * 32 + l31) * LD + 4 + 4 * h;
