@@ -66,6 +66,8 @@ SIGNATURES = {
     "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_wgan_gp_loss_fwd": (_i, [_f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
+    "eeggan_feature_match_fwd": (_i, [_f, _f, _f, _f, _i, _i, _st]),
+    "eeggan_feature_match_bwd": (_i, [_f, _f, _f, _i, _i, _st]),
     "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_mean_scale_bwd": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_swd_patches": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),

@@ -40,14 +40,17 @@ DISCRIMINATOR_KWARGS = dict(spectral=False, dropout=0.2, act_norm=None, group_si
                             conv_only=False, input_to_all_layers=False)
 
 
-def build_models(seed: int = RANDOM_SEED, generator_cls=None, discriminator_cls=None):
-    """Generator then Discriminator, constructed right after seeding torch, on the CPU."""
+def build_models(seed: int = RANDOM_SEED, generator_cls=None, discriminator_cls=None, shared=None, generator=None,
+                 discriminator=None):
+    """Generator then Discriminator, constructed right after seeding torch, on the CPU.  ``shared`` / ``generator`` /
+    ``discriminator``: overrides of the default constructor arguments (e.g. ``shared=dict(residual=True)``)."""
     if generator_cls is None:
         from .network import Discriminator, Generator
         generator_cls, discriminator_cls = Generator, Discriminator
     torch.manual_seed(seed)
-    g = generator_cls(**shared_model_kwargs(), z_distribution="normal", **GENERATOR_KWARGS)
-    d = discriminator_cls(**shared_model_kwargs(), **DISCRIMINATOR_KWARGS)
+    common = {**shared_model_kwargs(), **(shared or {})}
+    g = generator_cls(**common, z_distribution="normal", **{**GENERATOR_KWARGS, **(generator or {})})
+    d = discriminator_cls(**common, **{**DISCRIMINATOR_KWARGS, **(discriminator or {})})
     return g, d
 
 

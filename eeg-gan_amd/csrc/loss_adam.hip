@@ -297,7 +297,54 @@ int make_pack(const char* what, const eeggan_adam_tensor* table, int first, int 
 }  // namespace
 }  // namespace eeggan
 
+namespace eeggan {
+namespace {
+// Feature matching (reference losses.py:62-69): diff[f] = mean_b real[b,f] - mean_b fake[b,f], loss = mean_f diff^2.
+// One workgroup; thread f strides over the features and walks the batch (fixed order: deterministic).
+__global__ __launch_bounds__(256) void feature_match_fwd_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                                float* __restrict__ diff, float* __restrict__ loss, int B,
+                                                                int F) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float sr = 0.f, sf = 0.f;
+        for (int b = 0; b < B; ++b) {
+            sr += real[(long long)b * F + f];
+            sf += fake[(long long)b * F + f];
+        }
+        const float d = (sr - sf) / (float)B;
+        diff[f] = d;
+        acc += d * d;
+    }
+    const float tot = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss[0] = tot / (float)F;
+}
+// d loss / d fake[b,f] = -2 diff[f] / (B F), times the upstream scalar gradient
+__global__ __launch_bounds__(256) void feature_match_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ diff,
+                                                                float* __restrict__ g_fake, int B, int F) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * F) return;
+    g_fake[i] = -2.f * gl[0] * diff[i % F] / ((float)B * (float)F);
+}
+}  // namespace
+}  // namespace eeggan
+
 using namespace eeggan;
+
+extern "C" int eeggan_feature_match_fwd(const float* real, const float* fake, float* diff, float* loss, int B, int F,
+                                        void* stream) {
+    EEGGAN_REQUIRE(real && fake && diff && loss && B > 0 && F > 0, "feature_match_fwd: bad argument");
+    hipLaunchKernelGGL(feature_match_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), real, fake, diff, loss, B, F);
+    return check_launch("feature_match_fwd");
+}
+
+extern "C" int eeggan_feature_match_bwd(const float* gl, const float* diff, float* g_fake, int B, int F, void* stream) {
+    EEGGAN_REQUIRE(gl && diff && g_fake && B > 0 && F > 0, "feature_match_bwd: bad argument");
+    const long long n = (long long)B * F;
+    hipLaunchKernelGGL(feature_match_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), gl,
+                       diff, g_fake, B, F);
+    return check_launch("feature_match_bwd");
+}
 
 extern "C" int eeggan_wgan_gp_loss_fwd(const float* d_real, const float* d_fake, const float* g, float* norms,
                                        float* loss, int B, size_t per, float drift, float lambda, float target,

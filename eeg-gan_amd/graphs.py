@@ -377,7 +377,11 @@ class GraphedTrainer(Trainer):
         repeats = self.d_training_repeats
         real = cudize(next(self.dataiter))["x"]
         zs = [cudize(next(self.random_latents_generator))["z"] for _ in range(repeats + 1)]
-        key = (gen.depth, gen.alpha < 1.0, dis.alpha < 1.0, tuple(real.shape), tuple(zs[0].shape), repeats,
+        # (the options that fold the fade-in factor into kernel arguments instead of reading it from device memory
+        # -- the generator's summed signals, the critic's input at every stage -- need a new capture per value)
+        baked = (float(gen.alpha) if getattr(gen, "rgb_generation_mode", "pggan") != "pggan" else None,
+                 float(dis.alpha) if getattr(dis, "input_to_all_layers", False) else None)
+        key = (gen.depth, gen.alpha < 1.0, dis.alpha < 1.0, baked, tuple(real.shape), tuple(zs[0].shape), repeats,
                id(self.optimizer_d), id(self.optimizer_g),
                self.optimizer_d.param_groups[0]["lr"], self.optimizer_g.param_groups[0]["lr"])
         if key != self._key:

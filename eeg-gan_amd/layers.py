@@ -1,9 +1,10 @@
 """Layer modules with the names, constructor signatures and state-dict layout of the reference's
 ``layers.py``; every forward runs fused HIP kernels (see ``ops.py``).
 
-Supported: the options the default configuration uses (reference defaults.yml:16-58).  Options
-outside that set (spectral norm, separable convs, conditional batch norm, self attention, the
-residual helpers) raise ``NotImplementedError`` at construction: there is no second code path.
+Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
+non-equalized layers and the other initialisers.  Options outside that set (spectral norm, separable convs,
+conditional batch norm, self attention, the helpers of the ``deep`` blocks) raise ``NotImplementedError`` at
+construction: there is no second code path.
 """
 from __future__ import annotations
 

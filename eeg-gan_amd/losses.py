@@ -8,6 +8,7 @@ gradient exactly as the reference does (``autograd.grad(..., create_graph=True)`
 from __future__ import annotations
 
 import contextlib
+import random
 from typing import Optional
 
 import torch
@@ -94,19 +95,29 @@ def generator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_typ
     step (losses.py:75), so they are never used."""
     if loss_type not in LOSS_TYPES and not loss_type.startswith("wgan"):
         raise ValueError("Invalid loss type")
-    if random_multiply or feature_matching_lambda != 0.0:
-        raise NotImplementedError("random_multiply / feature matching are not supported")
     layers.drop_pool_reset()
     gen.zero_grad()
     g_, _ = gen(z)
     with (_frozen(dis) if skip_dis_weight_grads else contextlib.nullcontext()):
-        d_fake, _, _ = dis(g_)
+        d_fake, fake_features, _ = dis(g_)
+    real_features = None
+    # ``random_multiply``: the loss times a uniform draw from Python's generator (losses.py:46, 70), drawn here,
+    # where the reference draws it
+    scale = random.random() if random_multiply else 1.0
     if loss_type == "hinge" or loss_type.startswith("wgan"):
-        return ops.mean_scale(d_fake, -1.0)
-    with torch.no_grad():
-        d_real, _, _ = dis(real)
-    # the generator's relativistic losses are the critic's with the roles of the two score vectors swapped
-    return ops.score_loss(loss_type, d_fake.reshape(-1), d_real.reshape(-1))
+        g_loss = ops.mean_scale(d_fake, -1.0)
+    else:
+        with torch.no_grad():
+            d_real, real_features, _ = dis(real)
+        # the generator's relativistic losses are the critic's with the roles of the two score vectors swapped
+        g_loss = ops.score_loss(loss_type, d_fake.reshape(-1), d_real.reshape(-1))
+    if feature_matching_lambda != 0.0:
+        # (like the reference, losses.py:62-69, the term enters with weight one whatever the non-zero lambda is)
+        if real_features is None:
+            with torch.no_grad():
+                _, real_features, _ = dis(real)
+        g_loss = g_loss + ops.feature_match(real_features, fake_features)
+    return g_loss * scale if random_multiply else g_loss
 
 
 def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss_type: str,

@@ -2,9 +2,12 @@
 attributes and state-dict keys of the reference's ``network.py`` (GBlock 151-221,
 Generator 224-396, DBlock 399-449, Discriminator 452-560), running on the HIP kernels.
 
-Only the default configuration is accelerated; any other option raises
-``NotImplementedError`` in the constructor.  ``forward`` accepts either a tensor or the dict
-the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
+Beside the default configuration these options run on the kernels: ``residual`` blocks (identity or
+1x1-conv skips, network.py:195-199, 217-218, 435-438, 447-448), the generator's ``rgb_generation_mode``
+'residual' / 'mean' (network.py:332-349), ``no_tanh``, ``normalize_latents=False``, ReLU layers
+(``act_alpha=0``), non-equalized layers and the other initialisers, and the critic's ``input_to_all_layers``
+(network.py:533-549).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
 
@@ -32,8 +35,8 @@ class GBlock(nn.Module):
     def __init__(self, ch_in, ch_out, ch_rgb, k_size=3, initial_kernel_size=None, is_residual=False, no_tanh=False,
                  deep=False, per_channel_noise=False, to_rgb_mode="pggan", **layer_settings):
         super().__init__()
-        _require(not is_residual and not deep and not per_channel_noise and not no_tanh and to_rgb_mode == "pggan",
-                 "GBlock(residual/deep/per_channel_noise/no_tanh/to_rgb_mode)")
+        _require(not deep and not per_channel_noise and to_rgb_mode == "pggan",
+                 "GBlock(deep/per_channel_noise/to_rgb_mode)")
         first = initial_kernel_size is not None
         self.convs = nn.ModuleList([
             GeneralConv(ch_in, ch_out, kernel_size=initial_kernel_size if first else k_size,
@@ -41,12 +44,18 @@ class GBlock(nn.Module):
             GeneralConv(ch_out, ch_out, kernel_size=k_size, **layer_settings)])
         self.noises = None
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
-        self.to_rgb = ToRgb(GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings), ScaledTanh())
+        to_rgb = GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings)
+        self.to_rgb = to_rgb if no_tanh else ToRgb(to_rgb, ScaledTanh())  # (network.py:188-191)
         self.residual = None
+        if not first and is_residual:  # (network.py:195-197, constructed after to_rgb: same random stream)
+            self.residual = nn.Identity() if ch_in == ch_out else GeneralConv(ch_in, ch_out, 1, act_alpha=-1,
+                                                                              **rgb_settings)
         self.deep = False
 
     def forward(self, x, y=None, z=None, last=False):
         h = self.convs[1](self.convs[0](x))
+        if self.residual is not None:
+            h = ops.axpby(h, 1.0, self.residual(x), 1.0)
         return self.to_rgb(h) if last else h
 
 
@@ -59,10 +68,11 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not residual and not separable and not deep and not spectral, "residual/separable/deep/spectral")
+        _require(not separable and not deep and not spectral, "separable/deep/spectral")
         _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
-        _require(rgb_generation_mode == "pggan" and to_rgb_mode == "pggan" and not no_tanh and not per_channel_noise,
-                 "rgb_generation_mode/to_rgb_mode/no_tanh/per_channel_noise")
+        _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
+        if rgb_generation_mode not in ("pggan", "residual", "mean"):
+            raise ValueError("invalid rgb_generation_mode: {}".format(rgb_generation_mode))
         _require(act_norm in (None, "pixel"), f"act_norm={act_norm!r}")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
@@ -103,6 +113,22 @@ class Generator(nn.Module):
     def _grow(self, h, stage):
         return resample_signal(h, self.progression_scale_down[stage], self.progression_scale_up[stage])
 
+    def _combine_rgbs(self, saved):
+        """The signals of all stages so far, each resampled to the next one's length and added (network.py:332-349):
+        'residual' = their sum, 'mean' = their mean; during a fade-in the newest stage's signal enters with weight
+        alpha."""
+        total = saved[0]
+        for rgb in saved[1:]:
+            total = ops.axpby(resample_signal(total, total.shape[2], rgb.shape[2]), 1.0, rgb, 1.0)
+        n, alpha = len(saved), float(self.alpha)
+        if self.rgb_generation_mode == "residual":
+            return total if alpha == 1.0 else ops.axpby(total, 1.0, saved[-1], -(1.0 - alpha))
+        if alpha == 1.0:
+            return ops.axpby(total, 1.0 / n, None, 0.0) if n > 1 else total
+        # (mean * n - newest) / (n - 1) * (1 - alpha) + mean * alpha, with mean = total / n
+        ca = (1.0 - alpha) / (n - 1) + alpha / n
+        return ops.axpby(total, ca, saved[-1], -(1.0 - alpha) / (n - 1))
+
     def forward(self, z, y=None):
         if isinstance(z, dict):
             z = z["z"]
@@ -111,6 +137,14 @@ class Generator(nn.Module):
             z = pixel_norm(z)
         h = z.unsqueeze(2) if z.dim() == 2 else z
         d = self.depth
+        if self.rgb_generation_mode != "pggan":
+            saved = []
+            h = self.block0(h)
+            saved.append(self.block0.to_rgb(h))
+            for i in range(d):
+                h = self.blocks[i](self._grow(h, i))
+                saved.append(self.blocks[i].to_rgb(h))
+            return {"x": self._combine_rgbs(saved), "y": None}, {}
         if d == 0:
             return {"x": self.block0(h, last=True), "y": None}, {}
         h = self.block0(h)
@@ -130,7 +164,7 @@ class DBlock(nn.Module):
                  deep=False, group_size=4, temporal_groups_per_window=1, conv_disc=False, sinc=False,
                  **layer_settings):
         super().__init__()
-        _require(not is_residual and not deep and not conv_disc and not sinc, "DBlock(residual/deep/conv_disc/sinc)")
+        _require(not deep and not conv_disc and not sinc, "DBlock(deep/conv_disc/sinc)")
         last = initial_kernel_size is not None
         stats = last and group_size >= 0
         net = []
@@ -144,12 +178,18 @@ class DBlock(nn.Module):
         self.from_rgb = GeneralConv(ch_rgb, ch_in, kernel_size=1, act_alpha=layer_settings["act_alpha"],
                                     **rgb_settings)
         self.residual = None
+        if not last and is_residual:  # (network.py:431-438: the block with the full-length layer has no skip)
+            self.residual = nn.Identity() if ch_in == ch_out else GeneralConv(ch_in, ch_out, kernel_size=1,
+                                                                              act_alpha=-1, **rgb_settings)
         self.deep = False
 
     def forward(self, x, first=False):
         if first:
             x = self.from_rgb(x)
-        return self.net(x)
+        h = self.net(x)
+        if self.residual is not None:
+            h = ops.axpby(h, 1.0, self.residual(x), 1.0)
+        return h
 
 
 class Discriminator(nn.Module):
@@ -160,9 +200,8 @@ class Discriminator(nn.Module):
                  sinc=False):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not residual and not separable and not deep and not spectral, "residual/separable/deep/spectral")
-        _require(num_classes == 0 and not conv_only and not input_to_all_layers and not sinc,
-                 "conditioning/conv_only/input_to_all_layers/sinc")
+        _require(not separable and not deep and not spectral, "separable/deep/spectral")
+        _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
@@ -172,7 +211,7 @@ class Discriminator(nn.Module):
         self.alpha = 1.0
         # optional one-element device tensor mirroring alpha (kept current by graphs.GraphedTrainer)
         self.alpha_dev = None
-        self.input_to_all_layers = False
+        self.input_to_all_layers = input_to_all_layers
 
         def nf(stage):
             return min(max(int(fmap_base / (2.0 ** stage)), fmap_min), fmap_max)
@@ -207,9 +246,15 @@ class Discriminator(nn.Module):
         _require(y is None, "conditional discrimination")
         d = self.depth
         h = self.blocks[-(d + 1)](x, True)
+        x_low = None
         if d > 0:
             h = self._shrink(h, d - 1)
-            if self.alpha < 1.0:
+            if self.input_to_all_layers:
+                # every stage also sees the (down-sampled) input through its own from_rgb (network.py:533-549)
+                x_low = self._shrink(x, d - 1)
+                a = float(self.alpha)
+                h = ops.axpby(h, a / (1.0 + a), self.blocks[-d].from_rgb(x_low), 1.0 / (1.0 + a))
+            elif self.alpha < 1.0:
                 low = self.blocks[-d].from_rgb(self._shrink(x, d - 1))
                 alpha = self.alpha_dev if self.alpha_dev is not None else self.alpha
                 h = ops.blend(h, low, alpha)
@@ -217,6 +262,9 @@ class Discriminator(nn.Module):
             h = self.blocks[-i](h)
             if i > 1:
                 h = self._shrink(h, i - 2)
+                if self.input_to_all_layers:
+                    x_low = self._shrink(x_low, i - 2)
+                    h = ops.axpby(h, 0.5, self.blocks[-i + 1].from_rgb(x_low), 0.5)
         o = self.linear(h)
         if o.shape[2] != 1:
             o = resample_signal(o, o.shape[2], 1)  # mean over time as an average pool

@@ -1287,6 +1287,40 @@ def wgan_gp_d_loss(d_real, d_fake, g, drift, lam, target):
     return _WganGpLoss.apply(d_real, d_fake, g, float(drift), float(lam), float(target))
 
 
+class _FeatureMatch(Function):
+    """mean_f (mean_b real[b, f] - mean_b fake[b, f])^2, differentiable (once) in ``fake``."""
+
+    @staticmethod
+    def forward(ctx, real, fake):
+        real, fake = _chk(real, "features of the reals"), _chk(fake, "features of the fakes")
+        B = real.shape[0]
+        F = real.numel() // B
+        if fake.shape != real.shape:
+            raise RuntimeError(f"feature matching: {tuple(real.shape)} and {tuple(fake.shape)} features")
+        diff = torch.empty((F,), device=real.device, dtype=torch.float32)
+        loss = torch.empty((), device=real.device, dtype=torch.float32)
+        call("eeggan_feature_match_fwd", real.data_ptr(), fake.data_ptr(), diff.data_ptr(), loss.data_ptr(), B, F,
+             _stream())
+        ctx.save_for_backward(diff)
+        ctx.shape = fake.shape
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gl):
+        (diff,) = ctx.saved_tensors
+        gl = _chk(gl, "loss grad")
+        g_fake = torch.empty(ctx.shape, device=gl.device, dtype=torch.float32)
+        call("eeggan_feature_match_bwd", gl.data_ptr(), diff.data_ptr(), g_fake.data_ptr(), ctx.shape[0],
+             g_fake.numel() // ctx.shape[0], _stream())
+        return None, g_fake
+
+
+def feature_match(real_features, fake_features):
+    """The feature-matching term of the generator loss (reference losses.py:62-69)."""
+    return _FeatureMatch.apply(real_features.detach(), fake_features)
+
+
 class _MeanScale(Function):
     @staticmethod
     def forward(ctx, v, scale):

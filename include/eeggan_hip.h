@@ -258,6 +258,12 @@ int eeggan_grad_penalty_fwd(const float* g, float* norms, float* loss, int B, si
                             float target, int one_sided, void* stream);
 int eeggan_grad_penalty_bwd(const float* gl, const float* g, const float* norms, float* g_g, int B,
                             size_t per, float lambda, float target, int one_sided, void* stream);
+/* Feature matching term of the generator loss (losses.py:62-69) on the critic's features of reals and fakes,
+ * real / fake [B, F]:  diff[f] = mean_b real[b,f] - mean_b fake[b,f] (written for the backward),
+ * loss[0] = mean_f diff[f]^2;  bwd: g_fake[b,f] = gl[0] * d loss / d fake[b,f] = -2 gl[0] diff[f] / (B F). */
+int eeggan_feature_match_fwd(const float* real, const float* fake, float* diff, float* loss, int B, int F,
+                             void* stream);
+int eeggan_feature_match_bwd(const float* gl, const float* diff, float* g_fake, int B, int F, void* stream);
 /* out[0] = scale * mean(v[0..n))  (generator loss -mean(d_fake): scale = -1). */
 int eeggan_mean_scale(const float* v, float* out, int n, float scale, void* stream);
 /* out[i] = gl[0] * scale / n  for i in [0,n): backward of eeggan_mean_scale. */

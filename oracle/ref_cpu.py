@@ -52,6 +52,12 @@ class NetConfig:
     d_dropout: float = 0.2
     group_size: int = 4
     tanh_scale: float = 0.5
+    # options beside the defaults (network.py:152-153, 225-230, 400-401, 453-457)
+    residual: bool = False                 # identity / 1x1-conv skips around every block but the 32-sample ones
+    rgb_generation_mode: str = "pggan"     # 'residual' (sum of all stages' signals) | 'mean'
+    no_tanh: bool = False                  # to_rgb without the ScaledTanh
+    normalize_latents: bool = True
+    input_to_all_layers: bool = False      # the critic sees the down-sampled input at every stage
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -284,11 +290,28 @@ def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", f
     GDrop, the first one with the full-length kernel and pad = k-1 in the first block (network.py:157-159);
     ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
     ls = dict(act_alpha=cfg.act_alpha, norm="pixel", drop=cfg.g_dropout, src=src)
+    x = h
     h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
     h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
+    if cfg.residual and not first:  # network.py:195-199, 217-218
+        h = h + _skip(params, scales, f"{prefix}.residual", x)
     if last:
-        return torch.tanh(general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1) * cfg.tanh_scale)
+        return g_to_rgb(params, scales, prefix, h, cfg)
     return h
+
+
+def _skip(params, scales, path, x):
+    """The skip of a residual block: the identity when the block keeps the channel count, a linear 1x1 conv otherwise."""
+    if f"{path}.conv.conv.weight" in params:
+        return general_conv(x, params, scales, path, act_alpha=-1)
+    return x
+
+
+def g_to_rgb(params, scales, prefix, h, cfg: NetConfig):
+    """to_rgb: linear 1x1 conv, then ScaledTanh unless ``no_tanh`` (network.py:175-176, 188-191)."""
+    if cfg.no_tanh:
+        return general_conv(h, params, scales, f"{prefix}.to_rgb", act_alpha=-1)
+    return torch.tanh(general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1) * cfg.tanh_scale)
 
 
 def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", first: bool = False):
@@ -299,11 +322,18 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
     if first:
         h = general_conv(h, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
     if pos == cfg.num_stages:
+        if cfg.group_size < 0:  # no MinibatchStddev module in the block (network.py:405-406): the convs are net.0, net.1
+            h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
+            return general_conv(h, params, scales, f"blocks.{pos}.net.1", pad=0, **ls)
         h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
         h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
         return general_conv(h, params, scales, f"blocks.{pos}.net.2", pad=0, **ls)
+    x = h
     h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
-    return general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+    h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+    if cfg.residual:  # network.py:431-438, 447-448
+        h = h + _skip(params, scales, f"blocks.{pos}.residual", x)
+    return h
 
 
 def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfig,
@@ -316,11 +346,25 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
         return g_block(params, scales, prefix, h, cfg, src, first=first)
 
     def to_rgb(prefix, h):
-        c = general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1)
-        return torch.tanh(c * cfg.tanh_scale)  # layers.py:17-23
+        return g_to_rgb(params, scales, prefix, h, cfg)
 
-    h = pixel_norm(z).unsqueeze(2)
+    h = (pixel_norm(z) if cfg.normalize_latents else z).unsqueeze(2)
     h = gblock("block0", h, first=True)
+    if cfg.rgb_generation_mode != "pggan":
+        # network.py:332-349, 372-392: every stage's signal, each sum resampled to the next stage's length
+        saved = [to_rgb("block0", h)]
+        for i in range(depth):
+            h = gblock(f"blocks.{i}", resample(h, cfg.scale_down[i], cfg.scale_up[i]))
+            saved.append(to_rgb(f"blocks.{i}", h))
+        total = saved[0]
+        for rgb in saved[1:]:
+            total = resample(total, total.shape[2], rgb.shape[2]) + rgb
+        if cfg.rgb_generation_mode == "residual":
+            return total if alpha == 1.0 else total - (1.0 - alpha) * saved[-1]
+        total = total / len(saved)
+        if alpha == 1.0:
+            return total
+        return (total * len(saved) - saved[-1]) / (len(saved) - 1) * (1.0 - alpha) + total * alpha
     if depth == 0:
         return to_rgb("block0", h)
     for i in range(depth - 1):
@@ -348,16 +392,24 @@ def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetC
 
     first = R - depth                      # blocks[-(depth+1)]
     h = dblock(first, from_rgb(first, x))
+    x_low = None
     if depth > 0:
         up, dn = cfg.scale_up[depth - 1], cfg.scale_down[depth - 1]
         h = resample(h, up, dn)
-        if alpha < 1.0:
-            low = from_rgb(first + 1, resample(x, up, dn))
-            h = h * alpha + (1.0 - alpha) * low
+        if alpha < 1.0 or cfg.input_to_all_layers:
+            x_low = resample(x, up, dn)
+            low = from_rgb(first + 1, x_low)
+            if cfg.input_to_all_layers:  # network.py:537-538
+                h = (h * alpha + low) / (1.0 + alpha)
+            else:
+                h = h * alpha + (1.0 - alpha) * low
     for i in range(depth, 0, -1):
         h = dblock(R + 1 - i, h)
         if i > 1:
             h = resample(h, cfg.scale_up[i - 2], cfg.scale_down[i - 2])
+            if cfg.input_to_all_layers:  # network.py:546-549
+                x_low = resample(x_low, cfg.scale_up[i - 2], cfg.scale_down[i - 2])
+                h = (h + from_rgb(R + 2 - i, x_low)) / 2.0
     o = general_conv(h, params, scales, "linear", act_alpha=-1)
     return o.mean(dim=2).squeeze(), h
 
@@ -434,17 +486,31 @@ def d_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, mix, src_
     return loss, dict(d_real=d_real, d_fake=d_fake, fake=fake, gain=gain, gp_grad=g)
 
 
-def g_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, src_d, src_g):
-    """losses.py:40-60 (no feature matching, no random multiplier).  Call order: G(z), D(fake), and for the
-    relativistic losses D(real) without graph."""
+def g_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, src_d, src_g, random_multiply=False,
+               feature_matching_lambda=0.0):
+    """losses.py:40-70.  Call order: G(z), D(fake), and D(real) without graph for the relativistic losses (or,
+    after the loss, for the feature-matching term).  ``random_multiply`` draws its factor from Python's ``random``
+    right after the critic's pass over the fakes, like the reference (losses.py:46)."""
+    import random
     F = torch.nn.functional
     fake = generator_forward(gp_, gs, z, depth, alpha, cfg, src_g)
-    d_fake, _ = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
+    d_fake, fake_features = discriminator_forward(dp, ds, fake, depth, alpha, cfg, src_d)
     d_fake = d_fake.reshape(-1)
+    scale = random.random() if random_multiply else 1.0
+
+    def finish(loss, info, real_features=None):
+        if feature_matching_lambda != 0.0:  # losses.py:62-69 (the term's weight is one whatever the lambda)
+            if real_features is None:
+                with torch.no_grad():
+                    _, real_features = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
+            diff = real_features.mean(dim=0) - fake_features.mean(dim=0)
+            loss = loss + (diff * diff).mean()
+        return loss * scale, info
+
     if loss_type == "hinge" or loss_type.startswith("wgan"):
-        return -d_fake.mean(), dict(fake=fake, d_fake=d_fake)
+        return finish(-d_fake.mean(), dict(fake=fake, d_fake=d_fake))
     with torch.no_grad():
-        d_real, _ = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
+        d_real, real_features = discriminator_forward(dp, ds, real, depth, alpha, cfg, src_d)
     d_real = d_real.reshape(-1)
     ones, zeros = torch.ones_like(d_fake), torch.zeros_like(d_fake)
     if loss_type == "rsgan":
@@ -457,7 +523,7 @@ def g_loss_any(loss_type, dp, ds, gp_, gs, real, z, depth, alpha, cfg, src_d, sr
                 + torch.mean(F.relu(1.0 - (d_fake - torch.mean(d_real))))) / 2
     else:
         raise ValueError("Invalid loss type")
-    return loss, dict(fake=fake, d_fake=d_fake, d_real=d_real)
+    return finish(loss, dict(fake=fake, d_fake=d_fake, d_real=d_real), real_features)
 
 
 # --------------------------------------------------------------------------- schedule

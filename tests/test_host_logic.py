@@ -38,7 +38,7 @@ def test_unsupported_options_raise():
     from eeggan_amd.network import Discriminator, Generator
     kw = config.shared_model_kwargs()
     with pytest.raises(NotImplementedError):
-        Generator(**{**kw, "residual": True}, z_distribution="normal", **config.GENERATOR_KWARGS)
+        Generator(**{**kw, "deep": True}, z_distribution="normal", **config.GENERATOR_KWARGS)
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):

@@ -1,0 +1,200 @@
+"""Network and loss options beside the defaults: residual blocks (network.py:195-199, 217-218, 435-438, 447-448), the
+generator's 'residual' / 'mean' signal modes (332-349), the critic's input at every stage (533-549), plain layers
+(ReLU, no equalization, xavier init, to_rgb without tanh, latents not normalised, no MinibatchStddev) and the
+generator loss's random multiplier and feature-matching term (losses.py:46, 62-70).
+
+Fixture ``variants.npz`` (``tools/make_golden_variants.py``): per case one critic and one generator loss evaluation
+of the imported reference, 8 samples, in fp64 and fp32."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_fixture, oracle_params, rel, subsample
+
+NOISE_FACTOR, COND_EPS, COND_TRIALS, COND_CAP = 2.0, 1e-5, 4, 5e-3
+
+CASES = {
+    "residual": dict(shared=dict(residual=True)),
+    "residual_fade": dict(shared=dict(residual=True)),
+    "rgb_residual": dict(generator=dict(rgb_generation_mode="residual")),
+    "rgb_mean": dict(generator=dict(rgb_generation_mode="mean")),
+    "rgb_mean_full": dict(generator=dict(rgb_generation_mode="mean")),
+    "all_layers": dict(discriminator=dict(input_to_all_layers=True)),
+    "plain": dict(shared=dict(act_alpha=0.0, equalized=False, init="xavier_uniform"),
+                  generator=dict(no_tanh=True, normalize_latents=False), discriminator=dict(group_size=-1)),
+    "g_loss_opts": dict(random_multiply=True, feature_matching_lambda=1.0),
+    "g_loss_opts_rel": dict(random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
+}
+
+
+def _case(fx, name):
+    return {k[len(name) + 1:]: fx[k] for k in fx if k.startswith(name + ".")}
+
+
+def _models(case):
+    from eeggan_amd import config
+    return config.build_models(config.RANDOM_SEED, shared=case.get("shared"), generator=case.get("generator"),
+                               discriminator=case.get("discriminator"))
+
+
+def _oracle_config(case):
+    from oracle import ref_cpu as O
+    kw = {}
+    for src, keys in ((case.get("shared", {}), ("residual", "act_alpha")),
+                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents")),
+                      (case.get("discriminator", {}), ("input_to_all_layers", "group_size"))):
+        kw.update({k: src[k] for k in keys if k in src})
+    return O.NetConfig(**kw)
+
+
+def test_fixture_holds_every_case():
+    assert list(load_fixture("variants")["names"]) == list(CASES)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference(name):
+    from oracle import ref_cpu as O
+    fx = load_fixture("variants")
+    c, case = _case(fx, name), CASES[name]
+    depth, alpha, seed = int(c["depth"]), float(c["alpha"]), int(c["seed"])
+    loss_type = case.get("loss_type", "wgan_gp")
+    g, d = _models(case)
+    gp, gs = oracle_params(g)
+    dp, ds = oracle_params(d)
+    for p in list(gp.values()) + list(dp.values()):
+        p.requires_grad_(True)
+    real, z, mix = (torch.from_numpy(c[k]).double() for k in ("real", "z", "mix"))
+    cfg = _oracle_config(case)
+    np.random.seed(seed)
+    src = O.DropSource("numpy")
+    with torch.no_grad():
+        assert rel(O.generator_forward(gp, gs, z, depth, alpha, cfg, src), c["fake"]) < 1e-9
+        assert rel(O.discriminator_forward(dp, ds, real, depth, alpha, cfg, src)[0], c["score"]) < 1e-9
+    np.random.seed(seed + 1)
+    src = O.DropSource("numpy")
+    loss, _ = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+    assert abs(float(loss) - float(c["d_loss"])) < 1e-9 * max(1.0, abs(float(c["d_loss"])))
+    for k, gr in zip(dp.keys(), torch.autograd.grad(loss, list(dp.values()), allow_unused=True)):
+        assert (gr is None) == (f"d_none.{k}" in c) and (gr is None or rel(subsample(gr), c[f"d_sub.{k}"]) < 1e-9), k
+    np.random.seed(seed + 2)
+    random.seed(seed + 3)
+    src = O.DropSource("numpy")
+    loss, _ = O.g_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, src, src,
+                           random_multiply=case.get("random_multiply", False),
+                           feature_matching_lambda=case.get("feature_matching_lambda", 0.0))
+    assert abs(float(loss) - float(c["g_loss"])) < 1e-9 * max(1.0, abs(float(c["g_loss"])))
+    for k, gr in zip(gp.keys(), torch.autograd.grad(loss, list(gp.values()), allow_unused=True)):
+        assert (gr is None) == (f"g_none.{k}" in c) and (gr is None or rel(subsample(gr), c[f"g_sub.{k}"]) < 1e-9), k
+
+
+def test_options_outside_the_supported_set_still_raise():
+    from eeggan_amd import config
+    for kw in (dict(shared=dict(deep=True)), dict(shared=dict(separable=True)), dict(shared=dict(self_attention_layers=[1])),
+               dict(generator=dict(act_norm="batch")), dict(generator=dict(to_rgb_mode="sagan"))):
+        with pytest.raises(NotImplementedError):
+            config.build_models(1, **kw)
+    with pytest.raises(ValueError):
+        config.build_models(1, generator=dict(rgb_generation_mode="median"))
+
+
+@pytest.mark.gpu
+def test_feature_match_kernels(dev):
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    for B, F in ((8, 256), (5, 37), (32, 1000)):
+        r, f = torch.randn(B, F, 1, generator=gen), torch.randn(B, F, 1, generator=gen)
+        fd = f.double().requires_grad_(True)
+        diff = r.double().mean(dim=0) - fd.mean(dim=0)
+        want = (diff * diff).mean()
+        (wg,) = torch.autograd.grad(want, fd)
+        x = f.to(dev).requires_grad_(True)
+        got = ops.feature_match(r.to(dev), x)
+        (gg,) = torch.autograd.grad(got, x, torch.tensor(0.6, device=dev))
+        assert abs(float(got) - float(want)) < 1e-5 * float(want) and rel(gg, 0.6 * wg) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_against_reference_fixture(dev, name):
+    """Forward (fakes, scores) and loss values 1e-4; gradients per tensor within the gate of the other end-to-end
+    fixtures: max(1e-4, 2 x the reference's own fp32-vs-fp64 distance, min(2 x conditioning, 5e-3))."""
+    from eeggan_amd import layers, losses
+    fx = load_fixture("variants")
+    c, case = _case(fx, name), CASES[name]
+    depth, alpha, seed = int(c["depth"]), float(c["alpha"]), int(c["seed"])
+    loss_type = case.get("loss_type", "wgan_gp")
+    rm, fm = case.get("random_multiply", False), case.get("feature_matching_lambda", 0.0)
+    layers.set_drop_mode("numpy")
+    g, d = _models(case)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = alpha
+    real, z, mix = (torch.from_numpy(c[k]).to(dev) for k in ("real", "z", "mix"))
+    np.random.seed(seed)
+    with torch.no_grad():
+        assert rel(g({"z": z})[0]["x"], c["fake"]) < 1e-4
+        assert rel(d({"x": real})[0], c["score"]) < 1e-4
+
+    def evaluate(jitter=lambda t: t):
+        np.random.seed(seed + 1)
+        d_loss = losses.discriminator_loss(d, g, {"x": jitter(real)}, {"z": jitter(z)}, loss_type, 1e-3, 10.0, 1.0,
+                                           mixing=mix)
+        d_loss.backward()
+        d_grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in d.named_parameters()}
+        np.random.seed(seed + 2)
+        random.seed(seed + 3)
+        g_loss = losses.generator_loss(d, g, {"x": jitter(real)}, {"z": jitter(z)}, loss_type, rm, fm)
+        g_loss.backward()
+        g_grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in g.named_parameters()}
+        return d_loss, g_loss, {"d": d_grads, "g": g_grads}
+
+    d_loss, g_loss, grads = evaluate()
+    assert abs(float(d_loss) - float(c["d_loss"])) < 1e-4 * max(1.0, abs(float(c["d_loss"])))
+    assert abs(float(g_loss) - float(c["g_loss"])) < 1e-4 * max(1.0, abs(float(c["g_loss"])))
+    cond = {"d": {}, "g": {}}
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    for _ in range(COND_TRIALS):
+        _, _, pert = evaluate(lambda t: t * (1.0 + COND_EPS * torch.randn(t.shape, device=dev, generator=gen)))
+        for tag in ("d", "g"):
+            for k, a in grads[tag].items():
+                b = pert[tag][k]
+                if a is not None and b is not None and float(a.norm()) > 0.0:
+                    cond[tag][k] = max(cond[tag].get(k, 0.0), float((a - b).norm()) / float(a.norm()))
+    worst = 0.0
+    for tag in ("d", "g"):
+        for k, got in grads[tag].items():
+            if f"{tag}_none.{k}" in c:
+                assert got is None, f"{tag}.{k}: the reference leaves this gradient None"
+                continue
+            assert got is not None, f"{tag}.{k}: missing gradient"
+            noise = float(c[f"{tag}_noise.{k}"]) if f"{tag}_noise.{k}" in c else 0.0
+            tol = max(1e-4, NOISE_FACTOR * noise, min(NOISE_FACTOR * cond[tag].get(k, 0.0), COND_CAP))
+            e = rel(subsample(got), c[f"{tag}_sub.{k}"])
+            if f"{tag}_sub32.{k}" in c:
+                e = min(e, rel(subsample(got), c[f"{tag}_sub32.{k}"]))
+            worst = max(worst, e / tol)
+            assert e < tol, (f"{name} {tag}.{k}: {e:.3e} (tolerance {tol:.3e}, reference noise {noise:.1e}, "
+                             f"conditioning {cond[tag].get(k, 0.0):.1e})")
+    print(f"{name}: worst deviation = {worst:.2f} of its gate")
+
+
+@pytest.mark.gpu
+def test_graph_trainer_with_residual_blocks(dev):
+    """The graph trainer (stacked pass, two chains, grouped weight gradients) on networks with residual blocks and
+    the summed-signal generator follows the eager trainer."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models=dict(shared=dict(residual=True), generator=dict(rgb_generation_mode="residual")))
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        # (the graph trainer evaluates reals and fakes in one stacked pass: other tile shapes, other last bits; with the
+        # skips' additions the one-element bias of the output layer comes out at 1.2e-5 of its scale)
+        E._same_trajectory(base, graphed, "graph replay, residual blocks", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Golden fixture of the network and loss options beside the defaults (tests/golden/variants.npz), from the
+REFERENCE implementation (see make_golden.py for how it is imported and what is stored: numbers only).
+
+Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
+critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
+and the generator loss's random multiplier and feature-matching term.  Every case records one critic and one
+generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
+repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
+
+Usage: python tools/make_golden_variants.py [--out tests/golden]
+"""
+import argparse
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as M  # noqa: E402  (imports the reference with its two stubs)
+
+cfgmod, O, ref_network, ref_losses = M.cfgmod, M.O, M.ref_network, M.ref_losses
+
+CASES = {
+    "residual": dict(shared=dict(residual=True), depth=3, alpha=1.0),
+    "residual_fade": dict(shared=dict(residual=True), depth=2, alpha=0.6),
+    "rgb_residual": dict(generator=dict(rgb_generation_mode="residual"), depth=2, alpha=0.5),
+    "rgb_mean": dict(generator=dict(rgb_generation_mode="mean"), depth=2, alpha=0.5),
+    "rgb_mean_full": dict(generator=dict(rgb_generation_mode="mean"), depth=2, alpha=1.0),
+    "all_layers": dict(discriminator=dict(input_to_all_layers=True), depth=2, alpha=0.7),
+    "plain": dict(shared=dict(act_alpha=0.0, equalized=False, init="xavier_uniform"),
+                  generator=dict(no_tanh=True, normalize_latents=False), discriminator=dict(group_size=-1),
+                  depth=1, alpha=1.0),  # (ReLU feeds MinibatchStddev exact zeros, whose sqrt has no gradient: NaN in the reference)
+    "g_loss_opts": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=1.0),
+    "g_loss_opts_rel": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
+}
+
+
+def oracle_config(case):
+    kw = {}
+    sh, ge, di = case.get("shared", {}), case.get("generator", {}), case.get("discriminator", {})
+    if "residual" in sh:
+        kw["residual"] = sh["residual"]
+    if "act_alpha" in sh:
+        kw["act_alpha"] = sh["act_alpha"]
+    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents"):
+        if k in ge:
+            kw[k] = ge[k]
+    for k in ("input_to_all_layers", "group_size"):
+        if k in di:
+            kw[k] = di[k]
+    return O.NetConfig(**kw)
+
+
+def build_pair(case):
+    kw = dict(shared=case.get("shared"), generator=case.get("generator"), discriminator=case.get("discriminator"))
+    g_ref, d_ref = cfgmod.build_models(cfgmod.RANDOM_SEED, ref_network.Generator, ref_network.Discriminator, **kw)
+    g_my, d_my = cfgmod.build_models(cfgmod.RANDOM_SEED, **kw)
+    for a, b, nm in ((g_ref, g_my, "G"), (d_ref, d_my, "D")):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys()), f"{nm}: state-dict keys differ: {set(sa) ^ set(sb)}"
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), f"{nm}.{k}: initial weights differ"
+        assert M.scales_of(a) == M.scales_of(b), f"{nm}: equalized scales differ"
+    return g_ref, d_ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(M.REPO, "tests", "golden"))
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    batch = 8
+    fx = {"model_seed": np.array(cfgmod.RANDOM_SEED), "names": np.array(list(CASES))}
+    for idx, (name, case) in enumerate(CASES.items()):
+        seed = 301 + idx
+        depth, alpha = case["depth"], case["alpha"]
+        loss_type = case.get("loss_type", "wgan_gp")
+        rm, fm = case.get("random_multiply", False), case.get("feature_matching_lambda", 0.0)
+        T = cfgmod.seq_len(depth)
+        rng = np.random.default_rng(seed)
+        real32 = torch.from_numpy(O.synthetic_eeg(batch, cfgmod.NUM_CHANNELS, T, rng))
+        torch.manual_seed(seed)
+        z32 = torch.randn(batch, cfgmod.LATENT_SIZE)
+        mix32 = torch.rand(batch, 1, 1)
+
+        def run_ref(dtype):
+            g, d = build_pair(case)
+            g, d = g.to(dtype), d.to(dtype)
+            g.depth = d.depth = depth
+            g.alpha = d.alpha = alpha
+            ga, da = M.GAdapter(g), M.DAdapter(d)
+            real, z, mix = real32.to(dtype), z32.to(dtype), mix32.to(dtype)
+            np.random.seed(seed)
+            with torch.no_grad():
+                fake = g(z)[0]["x"]
+                score = d(real)[0]
+            np.random.seed(seed + 1)
+            orig = ref_losses.get_mixing_factor
+            ref_losses.get_mixing_factor = lambda b: mix
+            ref_losses.one, ref_losses.zero = torch.ones(batch).to(dtype), torch.zeros(batch).to(dtype)
+            try:
+                d_loss = ref_losses.discriminator_loss(da, ga, {"x": real}, {"z": z}, loss_type, 1e-3, 10.0, 1.0)
+            finally:
+                ref_losses.get_mixing_factor = orig
+            d_loss.backward()
+            d_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in d.named_parameters()}
+            np.random.seed(seed + 2)
+            random.seed(seed + 3)
+            g_loss = ref_losses.generator_loss(da, ga, {"x": real}, {"z": z}, loss_type, rm, fm)
+            g_loss.backward()
+            g_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
+            ref_losses.one = ref_losses.zero = None
+            return g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads
+
+        r32 = run_ref(torch.float32)
+        g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads = run_ref(torch.float64)
+        # the CPU restatement on the same draws
+        cfg = oracle_config(case)
+        gp, gs = M.to_oracle(g, torch.float64)
+        dp, ds = M.to_oracle(d, torch.float64)
+        for p in list(gp.values()) + list(dp.values()):
+            p.requires_grad_(True)
+        np.random.seed(seed)
+        src = O.DropSource("numpy")
+        with torch.no_grad():
+            ofake = O.generator_forward(gp, gs, z, depth, alpha, cfg, src)
+            oscore, _ = O.discriminator_forward(dp, ds, real, depth, alpha, cfg, src)
+        assert M.rel(ofake, fake) < 1e-9 and M.rel(oscore, score) < 1e-9, (name, M.rel(ofake, fake), M.rel(oscore, score))
+        np.random.seed(seed + 1)
+        src = O.DropSource("numpy")
+        ol, _ = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+        og = dict(zip(dp.keys(), torch.autograd.grad(ol, list(dp.values()), allow_unused=True)))
+        assert M.rel(ol, d_loss) < 1e-9, (name, "d_loss", M.rel(ol, d_loss))
+        for k, v in d_grads.items():
+            assert (v is None) == (og[k] is None) and (v is None or M.rel(og[k], v) < 1e-9), (name, k)
+        np.random.seed(seed + 2)
+        random.seed(seed + 3)
+        src = O.DropSource("numpy")
+        ol, _ = O.g_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, src, src, random_multiply=rm,
+                             feature_matching_lambda=fm)
+        og = dict(zip(gp.keys(), torch.autograd.grad(ol, list(gp.values()), allow_unused=True)))
+        assert M.rel(ol, g_loss) < 1e-9, (name, "g_loss", M.rel(ol, g_loss))
+        for k, v in g_grads.items():
+            assert (v is None) == (og[k] is None) and (v is None or M.rel(og[k], v) < 1e-9), (name, k)
+        fx[f"{name}.seed"], fx[f"{name}.depth"], fx[f"{name}.alpha"] = np.array(seed), np.array(depth), np.array(alpha)
+        fx[f"{name}.real"], fx[f"{name}.z"], fx[f"{name}.mix"] = real32.numpy(), z32.numpy(), mix32.numpy()
+        fx[f"{name}.fake"], fx[f"{name}.score"] = fake.numpy(), score.numpy()
+        fx[f"{name}.d_loss"], fx[f"{name}.g_loss"] = d_loss.detach().numpy(), g_loss.detach().numpy()
+        fx[f"{name}.d_loss32"], fx[f"{name}.g_loss32"] = r32[7].detach().numpy(), r32[9].detach().numpy()
+        for tag, grads, grads32 in (("d", d_grads, r32[8]), ("g", g_grads, r32[10])):
+            for k, v in grads.items():
+                if v is None:
+                    fx[f"{name}.{tag}_none.{k}"] = np.array(1)
+                else:
+                    fx[f"{name}.{tag}_sub.{k}"] = M.subsample(v)
+                    fx[f"{name}.{tag}_norm.{k}"] = np.array(float(v.norm()))
+                    if grads32[k] is not None:
+                        fx[f"{name}.{tag}_sub32.{k}"] = M.subsample(grads32[k])
+                        fx[f"{name}.{tag}_noise.{k}"] = np.array(M.rel(grads32[k], v))
+        print(f"{name}: depth {depth}, alpha {alpha}, d_loss {float(d_loss):.6f}, g_loss {float(g_loss):.6f}; "
+              f"weights identical, oracle matches", flush=True)
+    np.savez_compressed(os.path.join(args.out, "variants.npz"), **fx)
+
+
+if __name__ == "__main__":
+    main()
