@@ -42,6 +42,8 @@ SIGNATURES = {
                                          _st]),
     "eeggan_wgrad_reduce_multi": (_i, [C.c_void_p, _i, _st]),
     "eeggan_conv1d_wgrad_partial_multi": (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _st]),
+    "eeggan_dwconv1d": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _st]),
+    "eeggan_dwconv1d_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _i, _st]),
     "eeggan_head_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),
     "eeggan_head_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_head_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),

@@ -2,7 +2,8 @@
 ``layers.py``; every forward runs fused HIP kernels (see ``ops.py``).
 
 Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
-non-equalized layers and the other initialisers.  Options outside that set (spectral norm, separable convs,
+non-equalized layers and the other initialisers.  Separable layers (a depthwise conv followed
+by a 1x1 conv, layers.py:137-147) run too.  Options outside that set (spectral norm,
 conditional batch norm, self attention, the helpers of the ``deep`` blocks) raise ``NotImplementedError`` at
 construction: there is no second code path.
 """
@@ -161,7 +162,6 @@ def _unsupported(name):
 
 SelfAttention = _unsupported("SelfAttention")
 ConditionalBatchNorm = _unsupported("ConditionalBatchNorm")
-EqualizedSeparableConv1d = _unsupported("EqualizedSeparableConv1d")
 PassChannelResidual = _unsupported("PassChannelResidual")
 ConcatResidual = _unsupported("ConcatResidual")
 
@@ -175,8 +175,10 @@ class EqualizedConv1d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, padding, spectral, equalized, init, act_alpha, bias,
                  groups, stride):
         super().__init__()
-        if spectral or groups != 1 or stride != 1:
-            raise NotImplementedError("EqualizedConv1d: spectral norm, groups and strides are not supported")
+        if spectral or stride != 1 or (groups != 1 and not (groups == in_channels == out_channels)):
+            raise NotImplementedError("EqualizedConv1d: spectral norm, strides and groups other than 1 or the channel "
+                                      "count (depthwise) are not supported")
+        self.depthwise = groups != 1
         self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias,
                               groups=groups)
         w = self.conv.weight
@@ -207,9 +209,27 @@ class EqualizedConv1d(nn.Module):
         raise NotImplementedError(f"conv with kernel_size={k}, padding={pad} on length {x.shape[2]} is not supported")
 
     def forward(self, x):
+        if self.depthwise:
+            return ops.dwconv1d(x, self.conv.weight, self.conv.bias, self.scale, self.padding)
         if self.kind(x) != "same":
             raise NotImplementedError("a bare full-length conv is only available fused inside GeneralConv")
         return ops.conv1d(x, self.conv.weight, self.conv.bias, None, self.scale, ACT_NONE, flip=self._flip)
+
+
+class EqualizedSeparableConv1d(nn.Module):
+    """A depthwise conv (its own bias, no activation) followed by a 1x1 conv (reference layers.py:137-147).  Inside
+    GeneralConv the 1x1 half carries the layer's fused epilogue."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding, spectral, equalized, init, act_alpha, bias,
+                 groups, stride):
+        super().__init__()
+        self.net = nn.Sequential(
+            EqualizedConv1d(in_channels, in_channels, kernel_size, padding, spectral, equalized, init, -1, True,
+                            groups=in_channels, stride=stride),
+            EqualizedConv1d(in_channels, out_channels, 1, 0, spectral, equalized, init, act_alpha, bias, groups, 1))
+
+    def forward(self, x):
+        return self.net(x)
 
 
 class GeneralConv(nn.Module):
@@ -222,13 +242,13 @@ class GeneralConv(nn.Module):
                  act_alpha=0.2, do=0, num_classes=0, act_norm=None, spectral=False, init="kaiming_normal", bias=True,
                  separable=False, stride=1):
         super().__init__()
-        if separable or act_norm == "batch" or act_norm not in (None, "pixel"):
-            raise NotImplementedError("GeneralConv: separable convs and act_norm other than None/'pixel' "
-                                      "are not supported")
+        if act_norm == "batch" or act_norm not in (None, "pixel"):
+            raise NotImplementedError("GeneralConv: act_norm other than None/'pixel' is not supported")
         pad = (kernel_size - 1) // 2 if pad is None else pad
-        self.conv = EqualizedConv1d(in_channels, out_channels, kernel_size, padding=pad, spectral=spectral,
-                                    equalized=equalized, init=init, act_alpha=act_alpha, bias=bias, groups=1,
-                                    stride=stride)
+        conv_class = EqualizedSeparableConv1d if separable else EqualizedConv1d
+        self.conv = conv_class(in_channels, out_channels, kernel_size, padding=pad, spectral=spectral,
+                               equalized=equalized, init=init, act_alpha=act_alpha, bias=bias, groups=1, stride=stride)
+        self.separable = bool(separable)
         self.norm = None
         self.act_alpha = act_alpha
         self.act_norm = act_norm
@@ -245,12 +265,18 @@ class GeneralConv(nn.Module):
     def _multipliers(self, x):
         if self.drop is None:
             return None
-        return self.drop.sample(x.shape[0], self.conv.conv.out_channels, x.device)
+        pointwise = self.conv.net[1] if self.separable else self.conv
+        return self.drop.sample(x.shape[0], pointwise.conv.out_channels, x.device)
 
     def forward(self, x, y=None, z=None, conv_noise=None, _tanh_scale=None):
         if conv_noise is not None:
             raise NotImplementedError("per-channel conv noise is not supported")
         c = self.conv
+        if self.separable:
+            # the depthwise half (which also does the full-length layers' change of length), then the 1x1 half as an
+            # ordinary same-padded layer with this layer's epilogue
+            x = c.net[0](x)
+            c = c.net[1]
         w, b, s = c.conv.weight, c.conv.bias, c.scale
         kind = c.kind(x)
         slope = float(max(self.act_alpha, 0.0))

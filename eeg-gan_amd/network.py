@@ -5,7 +5,8 @@ Generator 224-396, DBlock 399-449, Discriminator 452-560), running on the HIP ke
 Beside the default configuration these options run on the kernels: ``residual`` blocks (identity or
 1x1-conv skips, network.py:195-199, 217-218, 435-438, 447-448), the generator's ``rgb_generation_mode``
 'residual' / 'mean' (network.py:332-349), ``no_tanh``, ``normalize_latents=False``, ReLU layers
-(``act_alpha=0``), non-equalized layers and the other initialisers, and the critic's ``input_to_all_layers``
+(``act_alpha=0``), non-equalized layers and the other initialisers, ``separable`` layers (layers.py:137-147) and
+the critic's ``input_to_all_layers``
 (network.py:533-549).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
@@ -68,7 +69,7 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not separable and not deep and not spectral, "separable/deep/spectral")
+        _require(not deep and not spectral, "deep/spectral")
         _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
         _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
@@ -200,7 +201,7 @@ class Discriminator(nn.Module):
                  sinc=False):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not separable and not deep and not spectral, "separable/deep/spectral")
+        _require(not deep and not spectral, "deep/spectral")
         _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)

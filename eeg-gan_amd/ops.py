@@ -703,6 +703,66 @@ def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None):
     return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip)
 
 
+# --------------------------------------------------------------------------------------- depthwise conv
+def _dw_raw(x, w, bias, pad, in_scale, flip):
+    x, w = _chk(x, "depthwise x"), _chk(w, "depthwise w")
+    B, Cc, T = x.shape
+    K = w.shape[2]
+    if tuple(w.shape) != (Cc, 1, K):
+        raise RuntimeError(f"depthwise conv: weight {tuple(w.shape)} does not match {Cc} channels")
+    y = torch.empty((B, Cc, T + 2 * pad - K + 1), device=x.device, dtype=torch.float32)
+    call("eeggan_dwconv1d", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, Cc, T, K, int(pad), float(in_scale),
+         int(flip), _stream())
+    return y
+
+
+class _DwWGrad(Function):
+    """Weight/bias gradient of the depthwise conv; a leaf of the second-order graph."""
+
+    @staticmethod
+    def forward(ctx, x, gy, K, pad, in_scale, flip, need_bias):
+        x, gy = _chk(x, "depthwise x"), _chk(gy, "depthwise gy")
+        B, Cc, T = x.shape
+        gw = torch.empty((Cc, 1, K), device=x.device, dtype=torch.float32)
+        gb = torch.empty((Cc,), device=x.device, dtype=torch.float32) if need_bias else None
+        call("eeggan_dwconv1d_wgrad", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), _p(gb), B, Cc, T, K, int(pad),
+             float(in_scale), int(flip), _stream())
+        return gw, gb
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("third-order differentiation through the depthwise weight gradient is not supported")
+
+
+class _DwConv(Function):
+    """y = bias + in_scale * depthwise_conv(x, w) (``flip``: with the taps reversed); linear in x and in w, so its
+    backward is built from itself and the weight-gradient op: differentiable to any order in x, twice in w."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, pad, in_scale, flip):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (pad, in_scale, flip, bias is not None)
+        return _dw_raw(x, w, bias, pad, in_scale, flip)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        pad, in_scale, flip, has_bias = ctx.cfg
+        gy = _chk(gy, "depthwise grad")
+        K = w.shape[2]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _DwConv.apply(gy, w, None, K - 1 - pad, in_scale, not flip)
+        if (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
+            gw, gb = _DwWGrad.apply(x, gy, K, pad, in_scale, flip, has_bias)
+        return gx, gw, gb, None, None, None
+
+
+def dwconv1d(x, w, bias, in_scale, pad):
+    """Depthwise (groups = channels) equalized conv: bias + conv(in_scale * x, w) with zero padding ``pad``."""
+    return _DwConv.apply(x, w, bias, int(pad), float(in_scale), False)
+
+
 # --------------------------------------------------------------------------------------- D tail
 class _MaskMul(Function):
     """out = g * drop * (y > 0 ? 1 : slope); linear in g, so its backward is itself."""

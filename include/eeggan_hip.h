@@ -131,6 +131,18 @@ typedef struct {
 int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, int njobs,
                                       eeggan_reduce_job* jobs_w, eeggan_reduce_job* jobs_b, void* stream);
 
+/* ---- depthwise Conv1d (groups = channels): the per-channel half of EqualizedSeparableConv1d (layers.py:137-147;
+ * its 1x1 half is eeggan_conv1d with K = 1) ----------------------------------------------------------------
+ *   y[b,c,t] = bias[c] + in_scale * sum_j w[c, flip ? K-1-j : j] * x[b,c,t+j-pad],  t in [0, Tin + 2 pad - K + 1)
+ * w [C, 1, K]; any K <= 64 and 0 <= pad < K (the full-length layers are K = 32 with pad = 31 or 0).  The input
+ * gradient is the same call on gy with flip toggled and pad' = K-1-pad (bias NULL).
+ *   wgrad: gw[c, flip ? K-1-j : j] = in_scale * sum_{b,t} gy[b,c,t] * x[b,c,t+j-pad];  gb[c] = sum_{b,t} gy[b,c,t]
+ * (gb may be NULL); sums in a fixed order. */
+int eeggan_dwconv1d(const float* x, const float* w, const float* bias, float* y, int B, int C, int Tin, int K,
+                    int pad, float in_scale, int flip, void* stream);
+int eeggan_dwconv1d_wgrad(const float* x, const float* gy, float* gw, float* gb, int B, int C, int Tin, int K,
+                          int pad, float in_scale, int flip, void* stream);
+
 /* ---- G head: Conv1d(k=KT, pad=KT-1) on a length-1 signal (network.py:158-159,302-303) --
  *   y[b,co,t] = drop[b,co]*act(bias[co] + in_scale * sum_ci w[co,ci,KT-1-t] * z[b,ci]),  t in [0,KT)
  * wgrad: gw[co,ci,KT-1-t] = in_scale * sum_b gy[b,co,t] * z[b,ci];  gb[co] = sum_{b,t} gy[b,co,t]

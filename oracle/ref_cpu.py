@@ -192,11 +192,21 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
                  src: Optional[DropSource] = None):
     """layers.py:207-213 for the default options: conv -> LeakyReLU ->
     (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
-    w = params[f"{path}.conv.conv.weight"]
-    b = params[f"{path}.conv.conv.bias"]
-    k = w.shape[2]
-    pad = (k - 1) // 2 if pad is None else pad
-    h = equalized_conv1d(x, w, b, scales[path], pad)
+    if f"{path}.conv.net.0.conv.weight" in params:
+        # separable layer (layers.py:137-147): a depthwise conv with its own scale and bias and the layer's padding,
+        # then a 1x1 conv; activation, norm and multiplier follow the pair
+        w0, b0 = params[f"{path}.conv.net.0.conv.weight"], params[f"{path}.conv.net.0.conv.bias"]
+        k = w0.shape[2]
+        pad = (k - 1) // 2 if pad is None else pad
+        h = F.conv1d(x * scales[f"{path}.conv.net.0"], w0, b0, padding=pad, groups=w0.shape[0])
+        h = equalized_conv1d(h, params[f"{path}.conv.net.1.conv.weight"], params[f"{path}.conv.net.1.conv.bias"],
+                             scales[f"{path}.conv.net.1"], 0)
+    else:
+        w = params[f"{path}.conv.conv.weight"]
+        b = params[f"{path}.conv.conv.bias"]
+        k = w.shape[2]
+        pad = (k - 1) // 2 if pad is None else pad
+        h = equalized_conv1d(x, w, b, scales[path], pad)
     if act_alpha >= 0:
         h = leaky_relu(h, act_alpha) if act_alpha > 0 else F.relu(h)
     if norm == "pixel":

@@ -24,7 +24,9 @@ def maxabs(a, b):
 
 
 def scales_of(module):
-    return {name[:-len(".conv")]: m.scale for name, m in module.named_modules()
+    # (key: the layer's path, i.e. the module's name without the ".conv" a plain layer ends in; the two halves of a
+    # separable layer, "... .conv.net.0" / "... .conv.net.1", keep their full names)
+    return {(name[:-len(".conv")] if name.endswith(".conv") else name): m.scale for name, m in module.named_modules()
             if type(m).__name__ == "EqualizedConv1d"}
 
 

@@ -24,6 +24,7 @@ CASES = {
     "all_layers": dict(discriminator=dict(input_to_all_layers=True)),
     "plain": dict(shared=dict(act_alpha=0.0, equalized=False, init="xavier_uniform"),
                   generator=dict(no_tanh=True, normalize_latents=False), discriminator=dict(group_size=-1)),
+    "separable": dict(shared=dict(separable=True)),
     "g_loss_opts": dict(random_multiply=True, feature_matching_lambda=1.0),
     "g_loss_opts_rel": dict(random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
 }
@@ -91,12 +92,38 @@ def test_oracle_matches_reference(name):
 
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
-    for kw in (dict(shared=dict(deep=True)), dict(shared=dict(separable=True)), dict(shared=dict(self_attention_layers=[1])),
+    for kw in (dict(shared=dict(deep=True)), dict(generator=dict(spectral=True)), dict(shared=dict(self_attention_layers=[1])),
                dict(generator=dict(act_norm="batch")), dict(generator=dict(to_rgb_mode="sagan"))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
         config.build_models(1, generator=dict(rgb_generation_mode="median"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 64, 256, 3, 1), (3, 256, 1, 32, 31), (5, 256, 32, 32, 0), (2, 37, 50, 5, 0)])
+def test_depthwise_conv_to_second_order(dev, shape):
+    """The depthwise kernels against torch's grouped conv in fp64: forward, input / weight / bias gradients, and the
+    gradient of a function of the input gradient (what the penalty's double backward asks for)."""
+    import torch.nn.functional as F
+    from eeggan_amd import ops
+    B, C, T, K, pad = shape
+    gen = torch.Generator().manual_seed(K)
+    x, w, b = torch.randn(B, C, T, generator=gen), torch.randn(C, 1, K, generator=gen), torch.randn(C, generator=gen)
+    s = 0.3
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv1d(xd * s, wd, bd, padding=pad, groups=C)
+    gy = torch.randn(yd.shape, generator=gen)
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    yg = ops.dwconv1d(xg, wg, bg, s, pad)
+    assert rel(yg, yd) < 2e-6
+    (gxd,) = torch.autograd.grad(yd, xd, gy.double(), create_graph=True)
+    (gxg,) = torch.autograd.grad(yg, xg, gy.to(dev), create_graph=True)
+    assert rel(gxg, gxd) < 2e-6
+    want = torch.autograd.grad((gxd ** 2).sum() + (yd * gy.double()).sum(), [xd, wd, bd], allow_unused=True)
+    got = torch.autograd.grad((gxg ** 2).sum() + (yg * gy.to(dev)).sum(), [xg, wg, bg], allow_unused=True)
+    for a, e, what in zip(got, want, ("input", "weight", "bias")):
+        assert rel(a, e) < 1e-5, (what, rel(a, e))
 
 
 @pytest.mark.gpu

@@ -33,6 +33,7 @@ CASES = {
     "plain": dict(shared=dict(act_alpha=0.0, equalized=False, init="xavier_uniform"),
                   generator=dict(no_tanh=True, normalize_latents=False), discriminator=dict(group_size=-1),
                   depth=1, alpha=1.0),  # (ReLU feeds MinibatchStddev exact zeros, whose sqrt has no gradient: NaN in the reference)
+    "separable": dict(shared=dict(separable=True), depth=2, alpha=1.0),
     "g_loss_opts": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=1.0),
     "g_loss_opts_rel": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
 }
