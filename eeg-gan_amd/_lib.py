@@ -57,6 +57,7 @@ SIGNATURES = {
     "eeggan_tanh_bwd": (_i, [_f, _f, _f, _sz, _fl, _st]),
     "eeggan_axpby": (_i, [_f, _fl, _f, _fl, _f, _sz, _st]),
     "eeggan_blend": (_i, [_f, _f, _f, _i, _f, _sz, _st]),
+    "eeggan_channel_window": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _st]),
     "eeggan_mix_batch": (_i, [_f, _f, _f, _f, _i, _sz, _st]),
     "eeggan_pow_base": (_i, [_f, _f, _sz, _fl, _st]),
     "eeggan_resample": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),

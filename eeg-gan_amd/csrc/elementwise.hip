@@ -595,6 +595,35 @@ extern "C" int eeggan_cast(const void* in, void* out, size_t n, int in_bf16, int
     return check_launch("cast");
 }
 
+// dst[b, cd, t] = (base ? base[b, cd, t] : 0) + (cd in [d0, d0 + n) ? src[b, s0 + cd - d0, Ts == 1 ? 0 : t] : 0) over the
+// WHOLE of dst [B, Cd, T]: channel slices, zero-padded placements and their sums (the skips of the `deep` blocks)
+__global__ __launch_bounds__(256) void channel_window_kernel(const float* __restrict__ src, const float* base, float* dst,
+                                                             int Cs, int Cd, int T, int Ts, int s0, int d0, int n,
+                                                             long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const long long r = i / T;
+        const int cd = (int)(r % Cd);
+        const long long b = r / Cd;
+        float v = base ? base[i] : 0.f;
+        const int c = cd - d0;
+        if (c >= 0 && c < n) v += src[(b * Cs + s0 + c) * Ts + (Ts == 1 ? 0 : t)];
+        dst[i] = v;
+    }
+}
+
+extern "C" int eeggan_channel_window(const float* src, const float* base, float* dst, int B, int Cs, int Cd, int T, int Ts,
+                                     int s0, int d0, int n, void* stream) {
+    EEGGAN_REQUIRE(src && dst, "channel_window: null pointer");
+    EEGGAN_REQUIRE(B > 0 && Cs > 0 && Cd > 0 && T > 0 && (Ts == T || Ts == 1), "channel_window: bad shape");
+    EEGGAN_REQUIRE(n > 0 && s0 >= 0 && d0 >= 0 && s0 + n <= Cs && d0 + n <= Cd, "channel_window: window [%d, %d) of %d "
+                   "source channels to [%d, %d) of %d", s0, s0 + n, Cs, d0, d0 + n, Cd);
+    const long long total = (long long)B * Cd * T;
+    hipLaunchKernelGGL(channel_window_kernel, dim3(blocks_for((size_t)total)), dim3(256), 0, as_stream(stream), src, base, dst,
+                       Cs, Cd, T, Ts, s0, d0, n, total);
+    return check_launch("channel_window");
+}
+
 extern "C" int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out, int B, size_t per,
                                 void* stream) {
     EEGGAN_REQUIRE(real && fake && mix && out && B > 0 && per > 0, "mix_batch: null pointer or empty");

@@ -4,7 +4,7 @@
 Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
 non-equalized layers and the other initialisers.  Separable layers (a depthwise conv followed
 by a 1x1 conv, layers.py:137-147) run too.  Options outside that set (spectral norm,
-conditional batch norm, self attention, the helpers of the ``deep`` blocks) raise ``NotImplementedError`` at
+conditional batch norm, self attention) raise ``NotImplementedError`` at
 construction: there is no second code path.
 """
 from __future__ import annotations
@@ -162,8 +162,18 @@ def _unsupported(name):
 
 SelfAttention = _unsupported("SelfAttention")
 ConditionalBatchNorm = _unsupported("ConditionalBatchNorm")
-PassChannelResidual = _unsupported("PassChannelResidual")
-ConcatResidual = _unsupported("ConcatResidual")
+
+
+class PassChannelResidual(nn.Module):
+    """x + y[:, :C] where C is x's channel count (reference layers.py:216-223, the branch that works for [B, C, T]
+    tensors: y has at least as many channels as x; a y of one time step is repeated over time, as broadcasting
+    does in the reference)."""
+
+    def forward(self, x, y):
+        if x.size(1) > y.size(1):
+            raise NotImplementedError("PassChannelResidual: a skip with fewer channels than the block's output "
+                                      "(the reference indexes a fourth dimension there and fails)")
+        return ops.channel_window(y, x, 0, 0, x.size(1))
 
 
 class EqualizedConv1d(nn.Module):
@@ -230,6 +240,24 @@ class EqualizedSeparableConv1d(nn.Module):
 
     def forward(self, x):
         return self.net(x)
+
+
+class ConcatResidual(nn.Module):
+    """h + cat([x, net(x)], dim=1) with ``net`` a linear 1x1 conv to the missing channels (reference
+    layers.py:226-239); h + x when the channel counts agree."""
+
+    def __init__(self, ch_in, ch_out, equalized, spectral, init):
+        super().__init__()
+        assert ch_out >= ch_in
+        self.net = GeneralConv(ch_in, ch_out - ch_in, kernel_size=1, equalized=equalized, act_alpha=-1,
+                               spectral=spectral, init=init) if ch_out > ch_in else None
+
+    def forward(self, h, x):
+        if self.net is None:
+            return ops.axpby(h, 1.0, x, 1.0)
+        out = ops.channel_window(x, h, 0, 0, x.size(1))
+        extra = self.net(x)
+        return ops.channel_window(extra, out, 0, x.size(1), extra.size(1))
 
 
 class GeneralConv(nn.Module):

@@ -5,7 +5,8 @@ Generator 224-396, DBlock 399-449, Discriminator 452-560), running on the HIP ke
 Beside the default configuration these options run on the kernels: ``residual`` blocks (identity or
 1x1-conv skips, network.py:195-199, 217-218, 435-438, 447-448), the generator's ``rgb_generation_mode``
 'residual' / 'mean' (network.py:332-349), ``no_tanh``, ``normalize_latents=False``, ReLU layers
-(``act_alpha=0``), non-equalized layers and the other initialisers, ``separable`` layers (layers.py:137-147) and
+(``act_alpha=0``), non-equalized layers and the other initialisers, ``separable`` layers (layers.py:137-147), ``deep`` blocks (four layers through a bottleneck with channel-slice /
+concatenation skips, network.py:157-169, 192-193, 407-418, 432-433) and
 the critic's ``input_to_all_layers``
 (network.py:533-549).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
@@ -16,7 +17,7 @@ import numpy as np
 from torch import nn
 
 from . import ops
-from .layers import GeneralConv, MinibatchStddev, ScaledTanh
+from .layers import ConcatResidual, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh
 from .utils import pixel_norm, resample_signal
 
 
@@ -36,26 +37,35 @@ class GBlock(nn.Module):
     def __init__(self, ch_in, ch_out, ch_rgb, k_size=3, initial_kernel_size=None, is_residual=False, no_tanh=False,
                  deep=False, per_channel_noise=False, to_rgb_mode="pggan", **layer_settings):
         super().__init__()
-        _require(not deep and not per_channel_noise and to_rgb_mode == "pggan",
-                 "GBlock(deep/per_channel_noise/to_rgb_mode)")
+        _require(not per_channel_noise and to_rgb_mode == "pggan", "GBlock(per_channel_noise/to_rgb_mode)")
         first = initial_kernel_size is not None
+        hidden = max((ch_in // 4) if deep else ch_out, 4)  # (network.py:157-169: four layers through a bottleneck)
         self.convs = nn.ModuleList([
-            GeneralConv(ch_in, ch_out, kernel_size=initial_kernel_size if first else k_size,
+            GeneralConv(ch_in, hidden, kernel_size=initial_kernel_size if first else k_size,
                         pad=initial_kernel_size - 1 if first else None, **layer_settings),
-            GeneralConv(ch_out, ch_out, kernel_size=k_size, **layer_settings)])
+            GeneralConv(hidden, hidden if deep else ch_out, kernel_size=k_size, **layer_settings)])
+        if deep:
+            self.convs.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
+            self.convs.append(GeneralConv(hidden, ch_out, kernel_size=k_size, **layer_settings))
         self.noises = None
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
         to_rgb = GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings)
         self.to_rgb = to_rgb if no_tanh else ToRgb(to_rgb, ScaledTanh())  # (network.py:188-191)
         self.residual = None
-        if not first and is_residual:  # (network.py:195-197, constructed after to_rgb: same random stream)
+        if deep:
+            self.residual = PassChannelResidual()
+        elif not first and is_residual:  # (network.py:195-197, constructed after to_rgb: same random stream)
             self.residual = nn.Identity() if ch_in == ch_out else GeneralConv(ch_in, ch_out, 1, act_alpha=-1,
                                                                               **rgb_settings)
-        self.deep = False
+        self.deep = deep
 
     def forward(self, x, y=None, z=None, last=False):
-        h = self.convs[1](self.convs[0](x))
-        if self.residual is not None:
+        h = x
+        for conv in self.convs:
+            h = conv(h)
+        if self.deep:
+            h = self.residual(h, x)
+        elif self.residual is not None:
             h = ops.axpby(h, 1.0, self.residual(x), 1.0)
         return self.to_rgb(h) if last else h
 
@@ -69,7 +79,7 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not deep and not spectral, "deep/spectral")
+        _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
         _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
@@ -108,7 +118,7 @@ class Generator(nn.Module):
         self.blocks = nn.ModuleList(
             [GBlock(nf(i + 1), nf(i + 2), **block_settings, **layer_settings) for i in range(stages)])
         self.max_depth = len(self.blocks)
-        self.deep = False
+        self.deep = deep
         self.rgb_generation_mode = rgb_generation_mode
 
     def _grow(self, h, stage):
@@ -165,29 +175,37 @@ class DBlock(nn.Module):
                  deep=False, group_size=4, temporal_groups_per_window=1, conv_disc=False, sinc=False,
                  **layer_settings):
         super().__init__()
-        _require(not deep and not conv_disc and not sinc, "DBlock(deep/conv_disc/sinc)")
+        _require(not conv_disc and not sinc, "DBlock(conv_disc/sinc)")
         last = initial_kernel_size is not None
         stats = last and group_size >= 0
+        hidden = max((ch_out // 4) if deep else ch_in, 4)  # (network.py:407-418)
         net = []
         if stats:
             net.append(MinibatchStddev(group_size, temporal_groups_per_window, initial_kernel_size))
-        net.append(GeneralConv(ch_in + (1 if stats else 0), ch_in, kernel_size=k_size, **layer_settings))
-        net.append(GeneralConv(ch_in, ch_out, kernel_size=initial_kernel_size if last else k_size,
+        net.append(GeneralConv(ch_in + (1 if stats else 0), hidden, kernel_size=k_size, **layer_settings))
+        if deep:
+            net.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
+            net.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
+        net.append(GeneralConv(hidden, ch_out, kernel_size=initial_kernel_size if last else k_size,
                                pad=0 if last else None, **layer_settings))
         self.net = nn.Sequential(*net)
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
         self.from_rgb = GeneralConv(ch_rgb, ch_in, kernel_size=1, act_alpha=layer_settings["act_alpha"],
                                     **rgb_settings)
         self.residual = None
-        if not last and is_residual:  # (network.py:431-438: the block with the full-length layer has no skip)
+        if not last and deep:  # (network.py:431-438: the block with the full-length layer has no skip)
+            self.residual = ConcatResidual(ch_in, ch_out, **rgb_settings)
+        elif not last and is_residual:
             self.residual = nn.Identity() if ch_in == ch_out else GeneralConv(ch_in, ch_out, kernel_size=1,
                                                                               act_alpha=-1, **rgb_settings)
-        self.deep = False
+        self.deep = deep
 
     def forward(self, x, first=False):
         if first:
             x = self.from_rgb(x)
         h = self.net(x)
+        if self.deep and self.residual is not None:
+            return self.residual(h, x)
         if self.residual is not None:
             h = ops.axpby(h, 1.0, self.residual(x), 1.0)
         return h
@@ -201,7 +219,7 @@ class Discriminator(nn.Module):
                  sinc=False):
         super().__init__()
         _require(not self_attention_layers, "self attention")
-        _require(not deep and not spectral, "deep/spectral")
+        _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)

@@ -1062,6 +1062,43 @@ def axpby(a, ca, b, cb):
     return _Axpby.apply(a, b, float(ca), float(cb))
 
 
+class _ChannelWindow(Function):
+    """out [B, Cd, T] = (base or 0) + src[:, s0:s0+n] placed at channels [d0, d0+n) (src with one time step is
+    repeated over time).  Linear in both operands and its own transpose with the roles of the windows swapped, so it
+    is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, src, base, s0, d0, n, Cd, T):
+        src = _chk(src, "channel window src")
+        B, Cs, Ts = src.shape
+        if base is not None:
+            base = _chk(base, "channel window base")
+            if tuple(base.shape) != (B, Cd, T):
+                raise RuntimeError(f"channel window: base {tuple(base.shape)} is not {(B, Cd, T)}")
+        out = torch.empty((B, Cd, T), device=src.device, dtype=torch.float32)
+        call("eeggan_channel_window", src.data_ptr(), _p(base), out.data_ptr(), B, Cs, Cd, T, Ts, int(s0), int(d0), int(n),
+             _stream())
+        ctx.cfg = (s0, d0, n, Cs, Ts, base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s0, d0, n, Cs, Ts, has_base = ctx.cfg
+        g_src = None
+        if ctx.needs_input_grad[0]:
+            if Ts != g.shape[2]:
+                raise NotImplementedError("gradient of a sample repeated over time (the latent of a deep first block)")
+            g_src = _ChannelWindow.apply(g, None, d0, s0, n, Cs, Ts)
+        return g_src, (g if has_base and ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+def channel_window(src, base, s0, d0, n, channels=None, length=None):
+    """``base + place(src[:, s0:s0+n] at channels d0..)`` (``base`` None: into zeros of ``channels`` x ``length``)."""
+    Cd = base.shape[1] if base is not None else int(channels)
+    T = base.shape[2] if base is not None else int(length if length is not None else src.shape[2])
+    return _ChannelWindow.apply(src, base, int(s0), int(d0), int(n), Cd, T)
+
+
 def _blend_raw(a, b, alpha, mode):
     a = _chk(a, "blend a", True)
     if b is not None:

@@ -194,6 +194,14 @@ int eeggan_axpby(const float* a, float ca, const float* b, float cb, float* out,
  *   mode 0: out = alpha*a + (1-alpha)*b;  mode 1: out = alpha*a;  mode 2: out = (1-alpha)*a  (b unused). */
 int eeggan_blend(const float* a, const float* b, const float* alpha, int mode, float* out, size_t n,
                  void* stream);
+/* Channel windows: over the whole of dst [B, Cd, T],
+ *   dst[b, cd, t] = (base ? base[b, cd, t] : 0) + (d0 <= cd < d0 + n ? src[b, s0 + cd - d0, t] : 0)
+ * with src [B, Cs, Ts], Ts = T or 1 (one sample repeated over time); base NULL, a [B, Cd, T] tensor, or dst itself.  The skips of the
+ * reference's `deep` blocks are made of it: y[:, :C] + x (PassChannelResidual, layers.py:216-223) and
+ * h + cat([x, net(x)], dim=1) (ConcatResidual, layers.py:226-239), and so are their gradients (a slice is a window
+ * into a smaller dst, its transpose a window into a zero-filled larger one). */
+int eeggan_channel_window(const float* src, const float* base, float* dst, int B, int Cs, int Cd, int T, int Ts,
+                          int s0, int d0, int n, void* stream);
 /* out[b,:] = mix[b]*real[b,:] + (1-mix[b])*fake[b,:]  (losses.py:107-108); per = C*T. */
 int eeggan_mix_batch(const float* real, const float* fake, const float* mix, float* out,
                      int B, size_t per, void* stream);

@@ -58,6 +58,7 @@ class NetConfig:
     no_tanh: bool = False                  # to_rgb without the ScaledTanh
     normalize_latents: bool = True
     input_to_all_layers: bool = False      # the critic sees the down-sampled input at every stage
+    deep: bool = False                     # blocks of four layers through a bottleneck, with slice / concatenation skips
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -303,7 +304,11 @@ def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", f
     x = h
     h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
     h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
-    if cfg.residual and not first:  # network.py:195-199, 217-218
+    if cfg.deep:  # network.py:167-169, 213-216; PassChannelResidual (layers.py:216-223): the input's first channels
+        h = general_conv(h, params, scales, f"{prefix}.convs.2", **ls)
+        h = general_conv(h, params, scales, f"{prefix}.convs.3", **ls)
+        h = x[:, :h.shape[1]] + h
+    elif cfg.residual and not first:  # network.py:195-199, 217-218
         h = h + _skip(params, scales, f"{prefix}.residual", x)
     if last:
         return g_to_rgb(params, scales, prefix, h, cfg)
@@ -336,11 +341,20 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
             h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
             return general_conv(h, params, scales, f"blocks.{pos}.net.1", pad=0, **ls)
         h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
-        h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
-        return general_conv(h, params, scales, f"blocks.{pos}.net.2", pad=0, **ls)
+        n = 4 if cfg.deep else 2  # (deep: two more layers in the middle, network.py:411-415)
+        for i in range(1, n):
+            h = general_conv(h, params, scales, f"blocks.{pos}.net.{i}", **ls)
+        return general_conv(h, params, scales, f"blocks.{pos}.net.{n}", pad=0, **ls)
     x = h
     h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
     h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
+    if cfg.deep:  # ConcatResidual (layers.py:226-239)
+        h = general_conv(h, params, scales, f"blocks.{pos}.net.2", **ls)
+        h = general_conv(h, params, scales, f"blocks.{pos}.net.3", **ls)
+        skip = f"blocks.{pos}.residual.net"
+        if f"{skip}.conv.conv.weight" in params:
+            return h + torch.cat([x, general_conv(x, params, scales, skip, act_alpha=-1)], dim=1)
+        return h + x
     if cfg.residual:  # network.py:431-438, 447-448
         h = h + _skip(params, scales, f"blocks.{pos}.residual", x)
     return h

@@ -38,7 +38,7 @@ def test_unsupported_options_raise():
     from eeggan_amd.network import Discriminator, Generator
     kw = config.shared_model_kwargs()
     with pytest.raises(NotImplementedError):
-        Generator(**{**kw, "deep": True}, z_distribution="normal", **config.GENERATOR_KWARGS)
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):
