@@ -1,5 +1,5 @@
 // In-kernel phase timing of the forward conv kernel (debugging aid, not part of the library).
-//   hipcc -O3 --offload-arch=gfx950 -DEEGGAN_TRACE scripts/conv_trace.hip eeg-gan_amd/csrc/lib.hip -o scripts/conv_trace
+//   hipcc -O3 --offload-arch=gfx950 -DEEGGAN_TRACE scripts/conv_trace.hip eeg-gan_amd/csrc/lib.hip eeg-gan_amd/csrc/conv_thin.hip -o scripts/conv_trace
 #include "../eeg-gan_amd/csrc/conv_mfma.hip"
 #include "../eeg-gan_amd/csrc/conv_ws.hip"
 

@@ -214,3 +214,72 @@ def test_graph_trainer_runs_in_the_mode(dev, bf16_storage):
         assert all(torch.isfinite(p).all() for p in list(tr.discriminator.parameters()) + list(tr.generator.parameters()))
     finally:
         layers.set_drop_mode("numpy")
+
+
+def test_layer_at_512_samples(dev, bf16_storage):
+    """The 64 -> 64 layer of the final stage at 512 samples per GPU (the configuration the mode is for): forward and
+    masked input gradient on a few samples against fp64 on the host, the weight gradient (which at this size is
+    submitted alone, in many splits) against an fp64 product of the same stored values on the device."""
+    from eeggan_amd import ops
+    from eeggan_amd._lib import ACT_LRELU
+    B, C, T, s = 512, 64, 1920, 0.07
+    gen = torch.Generator(device=dev).manual_seed(12)
+    x = torch.randn(B, C, T, generator=gen, device=dev).bfloat16()
+    gy = torch.randn(B, C, T, generator=gen, device=dev).bfloat16()
+    w = torch.randn(C, C, 3, generator=gen, device=dev)
+    b = torch.randn(C, generator=gen, device=dev)
+    r = torch.rand(B, C, generator=gen, device=dev) + 0.5
+    y = ops.conv1d_raw(x, w, b, r, in_scale=s, act=ACT_LRELU, act_param=0.2)
+    gx = ops.conv1d_raw(gy, w, None, None, in_scale=s, transposed=True, mask_y=y, mask_drop=r, mask_slope=0.2)
+    (gw, gb), = ops.conv1d_wgrad_group_raw([dict(x=x, gy=gy, K=3, in_scale=s, mask_y=y, mask_drop=r, mask_slope=0.2)])
+    assert y.dtype == gx.dtype == torch.bfloat16 and gw.dtype == torch.float32
+    pick = torch.tensor([0, 1, 255, 256, 510, 511])
+    wq = _r((w * s).cpu())
+    xs, gys, ys, rs = (t[pick.to(dev)].double().cpu() for t in (x, gy, y, r))
+    ref = F.leaky_relu(F.conv1d(xs, wq, b.double().cpu(), padding=1), 0.2) * rs[:, :, None]
+    assert rel(y[pick.to(dev)], ref) < ROUND
+    m = torch.where(ys > 0, 1.0, 0.2) * rs[:, :, None]
+    assert rel(gx[pick.to(dev)], F.conv_transpose1d(gys * m, wq, padding=1)) < ROUND
+    # weight gradient: every sample contributes; the masked gradient is an operand rounded to bfloat16
+    gm = (gy.float() * torch.where(y.float() > 0, 1.0, 0.2) * r[:, :, None])
+    gb_ref = gm.double().sum(dim=(0, 2))
+    gm = gm.bfloat16().double()
+    xp = F.pad(x.double(), (1, 1))
+    ref = s * torch.stack([torch.einsum("bot,bit->oi", gm, xp[:, :, j:j + T]) for j in range(3)], dim=2)
+    assert rel(gw, ref) < 1e-5, rel(gw, ref)
+    assert rel(gb, gb_ref) < 1e-5, rel(gb, gb_ref)
+
+
+def test_critic_iteration_at_512_samples_against_float32(dev, bf16_storage):
+    """One critic iteration at the final stage with 512 samples, eager, the reference's host noise: the mode against
+    the float32 arithmetic on the same inputs, to the bounds stated for it (the float32 step itself is held to the
+    oracle at sizes the oracle finishes; every kernel here takes the launch shapes of the large batch)."""
+    from eeggan_amd import config, layers, losses, ops
+    layers.set_drop_mode("numpy")
+    gen = torch.Generator().manual_seed(13)
+    B, depth = 512, 7
+    T = config.seq_len(depth)
+    real = (0.5 * torch.randn(B, config.NUM_CHANNELS, T, generator=gen)).to(dev)
+    z = torch.randn(B, config.LATENT_SIZE, generator=gen).to(dev)
+    mix = torch.rand(B, 1, 1, generator=gen).to(dev)
+    g, d = config.build_models(4)
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = 1.0
+    results = {}
+    for mode in ("bf16", "fp32"):
+        ops.set_storage(mode)
+        ops.set_precision(mode)
+        d.zero_grad(set_to_none=True)
+        np.random.seed(99)
+        with ops.direct_weight_grads():
+            loss = losses.discriminator_loss(d, g, {"x": real}, {"z": z}, "wgan_gp", 1e-3, 10.0, 1.0, mixing=mix)
+            loss.backward()
+        results[mode] = (float(loss), {k: p.grad.detach().clone() for k, p in d.named_parameters() if p.grad is not None})
+    ops.set_storage("bf16")
+    (l16, g16), (l32, g32) = results["bf16"], results["fp32"]
+    assert np.isfinite(l16) and abs(l16 - l32) < FWD_BOUND * max(1.0, abs(l32)), (l16, l32)
+    assert set(g16) == set(g32) and len(g32) > 30
+    worst = max((rel(g16[k], g32[k]), k) for k in g32 if float(g32[k].abs().max()) > 0)
+    print(f"512 samples, bf16 storage against float32: loss {l16:.5f} / {l32:.5f}, worst gradient {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < GRAD_BOUND, worst
