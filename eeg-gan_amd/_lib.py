@@ -71,6 +71,14 @@ SIGNATURES = {
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_feature_match_fwd": (_i, [_f, _f, _f, _f, _i, _i, _st]),
     "eeggan_feature_match_bwd": (_i, [_f, _f, _f, _i, _i, _st]),
+    "eeggan_bmm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _st]),
+    "eeggan_softmax_dim1_fwd": (_i, [_f, _f, _i, _i, _i, _st]),
+    "eeggan_softmax_dim1_bwd": (_i, [_f, _f, _f, _i, _i, _i, _st]),
+    "eeggan_softmax_dim1_bwd_dy": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
+    "eeggan_maxpool_fwd": (_i, [_f, _f, C.c_void_p, _sz, _i, _i, _st]),
+    "eeggan_maxpool_select": (_i, [_f, C.c_void_p, _f, _sz, _i, _i, _i, _st]),
+    "eeggan_dot_workspace": (_sz, []),
+    "eeggan_dot": (_i, [_f, _f, _f, _sz, C.c_void_p, _sz, _st]),
     "eeggan_mean_scale": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_mean_scale_bwd": (_i, [_f, _f, _i, _fl, _st]),
     "eeggan_swd_patches": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),

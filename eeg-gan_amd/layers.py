@@ -3,9 +3,8 @@
 
 Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
 non-equalized layers and the other initialisers.  Separable layers (a depthwise conv followed
-by a 1x1 conv, layers.py:137-147) run too.  Options outside that set (spectral norm,
-conditional batch norm, self attention) raise ``NotImplementedError`` at
-construction: there is no second code path.
+by a 1x1 conv, layers.py:137-147) and self attention (layers.py:41-64) run too.  Options outside that set
+(spectral norm, conditional batch norm) raise ``NotImplementedError`` at construction: there is no second code path.
 """
 from __future__ import annotations
 
@@ -160,8 +159,36 @@ def _unsupported(name):
     return _Unsupported
 
 
-SelfAttention = _unsupported("SelfAttention")
 ConditionalBatchNorm = _unsupported("ConditionalBatchNorm")
+
+
+class SelfAttention(nn.Module):
+    """out = gamma * final(value P) + x with P = softmax over the key positions of key^T query, key and value
+    max-pooled by 4 along time; query / key / value / final are linear 1x1 convs without bias and gamma is a scalar
+    parameter that starts at zero (reference layers.py:41-64).  Returns (out, P).  Twice differentiable (the critic's
+    gradient penalty passes through it).  float32 tensors only."""
+
+    def __init__(self, channels_in, spectral, init="xavier_uniform"):
+        super().__init__()
+        d_key = max(channels_in // 8, 2)
+        conf = dict(kernel_size=1, equalized=False, spectral=spectral, init=init, bias=False, act_alpha=-1)
+        self.gamma = nn.Parameter(torch.tensor(0.0), requires_grad=True)
+        self.pooling = nn.MaxPool1d(4)  # (parameter-less; kept for module-tree parity)
+        self.key_conv = GeneralConv(channels_in, d_key, **conf)
+        self.query_conv = GeneralConv(channels_in, d_key, **conf)
+        self.value_conv = GeneralConv(channels_in, channels_in // 2, **conf)
+        self.final_conv = GeneralConv(channels_in // 2, channels_in, **conf)
+        self.softmax = nn.Softmax(dim=-1)
+        self.scale = 1.0
+
+    def forward(self, x):
+        pool = self.pooling.kernel_size
+        query = self.query_conv(x)
+        key = ops.maxpool(self.key_conv(x), pool)
+        value = ops.maxpool(self.value_conv(x), pool)
+        attention = ops.softmax_dim1(ops.bmm(key, query, trans_a=True, alpha=1.0 / self.scale))
+        out = self.final_conv(ops.bmm(value, attention))
+        return ops.axpby(ops.mul_param(out, self.gamma), 1.0, x, 1.0), attention
 
 
 class PassChannelResidual(nn.Module):

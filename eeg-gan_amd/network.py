@@ -8,7 +8,7 @@ Beside the default configuration these options run on the kernels: ``residual`` 
 (``act_alpha=0``), non-equalized layers and the other initialisers, ``separable`` layers (layers.py:137-147), ``deep`` blocks (four layers through a bottleneck with channel-slice /
 concatenation skips, network.py:157-169, 192-193, 407-418, 432-433) and
 the critic's ``input_to_all_layers``
-(network.py:533-549).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+(network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -17,7 +17,7 @@ import numpy as np
 from torch import nn
 
 from . import ops
-from .layers import ConcatResidual, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh
+from .layers import ConcatResidual, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh, SelfAttention
 from .utils import pixel_norm, resample_signal
 
 
@@ -78,7 +78,6 @@ class Generator(nn.Module):
                  act_norm="pixel", conv_only=False, shared_embedding_size=32, normalize_latents=True,
                  rgb_generation_mode="pggan"):
         super().__init__()
-        _require(not self_attention_layers, "self attention")
         _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
         _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
@@ -114,14 +113,20 @@ class Generator(nn.Module):
                               do=dropout, num_classes=num_classes, act_norm=act_norm, bias=True, separable=separable)
         self.block0 = GBlock(latent_size, nf(1), initial_kernel_size=initial_kernel_size, **block_settings,
                              **layer_settings)
-        self.self_attention = dict()
+        self.self_attention = dict()  # (network.py:304-310: stage -> layer; registered through ``dummy``)
+        attention = [SelfAttention(nf(layer + 1), spectral, init) for layer in self_attention_layers or ()]
+        self.self_attention.update(zip(self_attention_layers or (), attention))
+        if attention:
+            self.dummy = nn.ModuleList(attention)
         self.blocks = nn.ModuleList(
             [GBlock(nf(i + 1), nf(i + 2), **block_settings, **layer_settings) for i in range(stages)])
         self.max_depth = len(self.blocks)
         self.deep = deep
         self.rgb_generation_mode = rgb_generation_mode
 
-    def _grow(self, h, stage):
+    def _grow(self, h, stage, maps=None):
+        if maps is not None and stage in self.self_attention:  # (network.py:324-330: before the stage grows)
+            h, maps[stage] = self.self_attention[stage](h)
         return resample_signal(h, self.progression_scale_down[stage], self.progression_scale_up[stage])
 
     def _combine_rgbs(self, saved):
@@ -148,26 +153,27 @@ class Generator(nn.Module):
             z = pixel_norm(z)
         h = z.unsqueeze(2) if z.dim() == 2 else z
         d = self.depth
+        maps = {}  # attention maps by stage; the newest stage never gets the layer (network.py:383-390)
         if self.rgb_generation_mode != "pggan":
             saved = []
             h = self.block0(h)
             saved.append(self.block0.to_rgb(h))
             for i in range(d):
-                h = self.blocks[i](self._grow(h, i))
+                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None))
                 saved.append(self.blocks[i].to_rgb(h))
-            return {"x": self._combine_rgbs(saved), "y": None}, {}
+            return {"x": self._combine_rgbs(saved), "y": None}, maps
         if d == 0:
-            return {"x": self.block0(h, last=True), "y": None}, {}
+            return {"x": self.block0(h, last=True), "y": None}, maps
         h = self.block0(h)
         for i in range(d - 1):
-            h = self.blocks[i](self._grow(h, i))
+            h = self.blocks[i](self._grow(h, i, maps))
         h = self._grow(h, d - 1)
         ult = self.blocks[d - 1](h, last=True)
         if self.alpha == 1.0:
-            return {"x": ult, "y": None}, {}
+            return {"x": ult, "y": None}, maps
         prev = self.blocks[d - 2] if d > 1 else self.block0
         alpha = self.alpha_dev if self.alpha_dev is not None else self.alpha
-        return {"x": ops.blend(ult, prev.to_rgb(h), alpha), "y": None}, {}
+        return {"x": ops.blend(ult, prev.to_rgb(h), alpha), "y": None}, maps
 
 
 class DBlock(nn.Module):
@@ -218,7 +224,6 @@ class Discriminator(nn.Module):
                  temporal_groups_per_window=1, conv_only=False, input_to_all_layers=False, initial_sampling_rate=1.0,
                  sinc=False):
         super().__init__()
-        _require(not self_attention_layers, "self attention")
         _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
@@ -246,7 +251,11 @@ class Discriminator(nn.Module):
                             sample_rate=initial_sampling_rate, **block_settings, **layer_settings)
         up, down = np.array(progression_scale_up), np.array(progression_scale_down)
         lens = [initial_kernel_size * np.sum(up[:i] / down[:i]) for i in range(stages + 1)]
-        self.self_attention = dict()
+        self.self_attention = dict()  # (network.py:503-509)
+        attention = [SelfAttention(nf(layer + 1), spectral, init) for layer in self_attention_layers or ()]
+        self.self_attention.update(zip(self_attention_layers or (), attention))
+        if attention:
+            self.dummy = nn.ModuleList(attention)
         self.blocks = nn.ModuleList(
             [DBlock(nf(i + 2), nf(i + 1), sample_rate=lens[i + 1] * initial_sampling_rate / initial_kernel_size,
                     **block_settings, **layer_settings) for i in range(stages - 1, -1, -1)] + [last_block])
@@ -264,6 +273,7 @@ class Discriminator(nn.Module):
             x = x["x"]
         _require(y is None, "conditional discrimination")
         d = self.depth
+        maps = {}
         h = self.blocks[-(d + 1)](x, True)
         x_low = None
         if d > 0:
@@ -284,7 +294,9 @@ class Discriminator(nn.Module):
                 if self.input_to_all_layers:
                     x_low = self._shrink(x_low, i - 2)
                     h = ops.axpby(h, 0.5, self.blocks[-i + 1].from_rgb(x_low), 0.5)
+            if (i - 2) in self.self_attention:  # (network.py:550-553)
+                h, maps[i] = self.self_attention[i - 2](h)
         o = self.linear(h)
         if o.shape[2] != 1:
             o = resample_signal(o, o.shape[2], 1)  # mean over time as an average pool
-        return o.reshape(o.shape[0]), h, {}
+        return o.reshape(o.shape[0]), h, maps

@@ -1151,6 +1151,189 @@ def blend(a, b, alpha):
     return _Axpby.apply(a, b, float(al), float(np.float32(1.0) - al))
 
 
+# --------------------------------------------------------------------------------------- self attention pieces
+def _bmm_raw(a, b, ta, tb, alpha=1.0):
+    a, b = _chk(a, "bmm a"), _chk(b, "bmm b")
+    if a.dim() != 3 or b.dim() != 3 or a.shape[0] != b.shape[0]:
+        raise RuntimeError(f"bmm: operands {tuple(a.shape)} and {tuple(b.shape)}")
+    M, K = (a.shape[2], a.shape[1]) if ta else (a.shape[1], a.shape[2])
+    Kb, N = (b.shape[2], b.shape[1]) if tb else (b.shape[1], b.shape[2])
+    if K != Kb:
+        raise RuntimeError(f"bmm: reduction lengths differ ({K} vs {Kb})")
+    out = torch.empty((a.shape[0], M, N), device=a.device, dtype=torch.float32)
+    call("eeggan_bmm", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.shape[0], M, N, K, int(ta), int(tb), float(alpha),
+         _stream())
+    return out
+
+
+class _Bmm(Function):
+    """alpha * op(a) op(b) per batch entry, op = transpose of the stored matrix where the flag is set.  Its gradients
+    are products of the same kind, so it is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, a, b, ta, tb, alpha):
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (ta, tb, alpha)
+        return _bmm_raw(a, b, ta, tb, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.cfg
+        g = _chk(g, "bmm cotangent")
+        ga = gb = None
+        if ctx.needs_input_grad[0]:  # d op(a) = g op(b)^T
+            ga = _Bmm.apply(b, g, tb, True, alpha) if ta else _Bmm.apply(g, b, False, not tb, alpha)
+        if ctx.needs_input_grad[1]:  # d op(b) = op(a)^T g
+            gb = _Bmm.apply(g, a, True, ta, alpha) if tb else _Bmm.apply(a, g, not ta, False, alpha)
+        return ga, gb, None, None, None
+
+
+def bmm(a, b, trans_a=False, trans_b=False, alpha=1.0):
+    return _Bmm.apply(a, b, bool(trans_a), bool(trans_b), float(alpha))
+
+
+class _SoftmaxBwd(Function):
+    """gx = y (gy - sum_m gy y), differentiable once more in both operands."""
+
+    @staticmethod
+    def forward(ctx, gy, y):
+        gy, y = _chk(gy, "softmax cotangent"), _chk(y, "softmax output")
+        ctx.save_for_backward(gy, y)
+        gx = torch.empty_like(y)
+        call("eeggan_softmax_dim1_bwd", gy.data_ptr(), y.data_ptr(), gx.data_ptr(), *y.shape, _stream())
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, q):
+        gy, y = ctx.saved_tensors
+        q = _chk(q, "softmax second-order cotangent")
+        d_gy = d_y = None
+        if ctx.needs_input_grad[0]:
+            d_gy = torch.empty_like(y)
+            call("eeggan_softmax_dim1_bwd", q.data_ptr(), y.data_ptr(), d_gy.data_ptr(), *y.shape, _stream())
+        if ctx.needs_input_grad[1]:
+            d_y = torch.empty_like(y)
+            call("eeggan_softmax_dim1_bwd_dy", q.data_ptr(), gy.data_ptr(), y.data_ptr(), d_y.data_ptr(), *y.shape,
+                 _stream())
+        return d_gy, d_y
+
+
+class _Softmax(Function):
+    @staticmethod
+    def forward(ctx, s):
+        s = _chk(s, "softmax input")
+        if s.dim() != 3:
+            raise RuntimeError("softmax over dim 1 takes a [B, M, N] tensor")
+        p = torch.empty_like(s)
+        call("eeggan_softmax_dim1_fwd", s.data_ptr(), p.data_ptr(), *s.shape, _stream())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        p, = ctx.saved_tensors
+        return _SoftmaxBwd.apply(g, p)
+
+
+def softmax_dim1(s):
+    """softmax over dim 1 of a [B, M, N] tensor (twice differentiable)."""
+    return _Softmax.apply(s)
+
+
+class _PoolSelect(Function):
+    """Max pooling with the positions of the maxima fixed (``idx``): the gather (scatter = False) and the scatter are
+    each other's transposes, so both are differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, src, idx, t_in, pool, scatter):
+        src = _chk(src, "maxpool select src")
+        ctx.cfg = (idx, t_in, pool, scatter)
+        rows = idx.numel() // (t_in // pool)
+        t_out = t_in if scatter else t_in // pool
+        if src.numel() != rows * (t_in // pool if scatter else t_in):
+            raise RuntimeError("maxpool select: source does not match the pooled shape")
+        dst = torch.empty(src.shape[:-1] + (t_out,), device=src.device, dtype=torch.float32)
+        call("eeggan_maxpool_select", src.data_ptr(), idx.data_ptr(), dst.data_ptr(), rows, t_in, pool, int(scatter), _stream())
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, t_in, pool, scatter = ctx.cfg
+        return _PoolSelect.apply(g, idx, t_in, pool, not scatter), None, None, None, None
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x, pool):
+        x = _chk(x, "maxpool input")
+        t_in = x.shape[-1]
+        if t_in % pool:
+            raise NotImplementedError("max pooling of a length that is not a multiple of the window")
+        y = torch.empty(x.shape[:-1] + (t_in // pool,), device=x.device, dtype=torch.float32)
+        idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+        call("eeggan_maxpool_fwd", x.data_ptr(), y.data_ptr(), idx.data_ptr(), x.numel() // t_in, t_in, pool, _stream())
+        ctx.cfg = (idx, t_in, pool)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, t_in, pool = ctx.cfg
+        return _PoolSelect.apply(g, idx, t_in, pool, True), None
+
+
+def maxpool(x, pool):
+    """nn.MaxPool1d(pool) along the last axis (twice differentiable: linear once the maxima are located)."""
+    return _MaxPool.apply(x, int(pool))
+
+
+class _Dot(Function):
+    """sum(a * b) as a 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "dot a"), _chk(b, "dot b")
+        if a.shape != b.shape:
+            raise RuntimeError("dot: shapes differ")
+        ctx.save_for_backward(a, b)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        nbytes = _lib.load().eeggan_dot_workspace()
+        ws = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+        call("eeggan_dot", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), ws.data_ptr(), nbytes, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, q):
+        a, b = ctx.saved_tensors
+        q = q.contiguous()
+        ga = _MulParam.apply(b, q) if ctx.needs_input_grad[0] else None
+        gb = _MulParam.apply(a, q) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+class _MulParam(Function):
+    """s * f with s a one-element tensor in device memory (a scalar parameter): read by the kernel at run time, so a
+    captured graph follows the parameter as the optimizer moves it.  Differentiable to any order in both operands."""
+
+    @staticmethod
+    def forward(ctx, f, s):
+        ctx.save_for_backward(f, s)
+        return _blend_raw(f, None, s, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        f, s = ctx.saved_tensors
+        g = _chk(g, "scalar-multiple cotangent")
+        gf = _MulParam.apply(g, s) if ctx.needs_input_grad[0] else None
+        gs = _Dot.apply(g, f).reshape(s.shape) if ctx.needs_input_grad[1] else None
+        return gf, gs
+
+
+def mul_param(f, s):
+    return _MulParam.apply(f, s)
+
+
 # --------------------------------------------------------------------------------------- minibatch stddev
 # ``segments``: the batch is a concatenation of that many independent minibatches (e.g. reals and
 # fakes stacked into one critic pass); the group statistics never mix samples of two segments, so

@@ -284,6 +284,35 @@ int eeggan_grad_penalty_bwd(const float* gl, const float* g, const float* norms,
 int eeggan_feature_match_fwd(const float* real, const float* fake, float* diff, float* loss, int B, int F,
                              void* stream);
 int eeggan_feature_match_bwd(const float* gl, const float* diff, float* g_fake, int B, int F, void* stream);
+/* ---- self attention (SelfAttention, layers.py:41-64): out = gamma * Wf (value P) + x with
+ * P = softmax over dim 1 of key^T query, key / value max-pooled by 4 along time.  The 1x1 convs are eeggan_conv1d;
+ * the rest is made of the entry points below (float32 tensors). ------------------------------------------------ */
+/* Batched product c[b] (M x N) = alpha * op(a[b]) op(b[b]) of dense row-major matrices: a[b] is stored M x K, or
+ * K x M when trans_a; b[b] K x N, or N x K when trans_b (torch.bmm at layers.py:60,62 and every gradient of the two). */
+int eeggan_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int trans_a, int trans_b,
+               float alpha, void* stream);
+/* p = softmax(s, dim=1) for s [B, M, N] (F.softmax(..., dim=1), layers.py:60). */
+int eeggan_softmax_dim1_fwd(const float* s, float* p, int B, int M, int N, void* stream);
+/* gx = y * (gy - sum_m gy y): backward of that softmax given its output y; also the derivative of this expression
+ * with respect to gy, applied to a cotangent passed as gy. */
+int eeggan_softmax_dim1_bwd(const float* gy, const float* y, float* gx, int B, int M, int N, void* stream);
+/* The derivative of gx = y (gy - sum_m gy y) with respect to y applied to the cotangent q:
+ * out = q (gy - sum_m gy y) - gy sum_m(q y)   (second-order pass of the gradient penalty). */
+int eeggan_softmax_dim1_bwd_dy(const float* q, const float* gy, const float* y, float* out, int B, int M, int N,
+                               void* stream);
+/* nn.MaxPool1d(pool) along the last axis of x [rows, Tin] (layers.py:48,58-59): y [rows, Tin / pool] and the position
+ * of each maximum inside its window (first one on ties), idx [rows, Tin / pool] bytes. */
+int eeggan_maxpool_fwd(const float* x, float* y, unsigned char* idx, size_t rows, int Tin, int pool, void* stream);
+/* With the positions fixed the pooling is linear: scatter = 0: dst [rows, Tin / pool] = src[r, pool t + idx[r, t]]
+ * (the pooling applied to another tensor: backward of the scatter); scatter = 1: dst [rows, Tin] = src [rows, Tin / pool]
+ * placed at the maxima, zero elsewhere (backward of the pooling). */
+int eeggan_maxpool_select(const float* src, const unsigned char* idx, float* dst, size_t rows, int Tin, int pool,
+                          int scatter, void* stream);
+/* out[0] = sum_i a[i] b[i], summed in double in a fixed order (gradient of the scalar gamma, layers.py:47,64).
+ * workspace: eeggan_dot_workspace() bytes of device memory. */
+size_t eeggan_dot_workspace(void);
+int eeggan_dot(const float* a, const float* b, float* out, size_t n, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[0] = scale * mean(v[0..n))  (generator loss -mean(d_fake): scale = -1). */
 int eeggan_mean_scale(const float* v, float* out, int n, float scale, void* stream);
 /* out[i] = gl[0] * scale / n  for i in [0,n): backward of eeggan_mean_scale. */

@@ -59,6 +59,7 @@ class NetConfig:
     normalize_latents: bool = True
     input_to_all_layers: bool = False      # the critic sees the down-sampled input at every stage
     deep: bool = False                     # blocks of four layers through a bottleneck, with slice / concatenation skips
+    self_attention_layers: Sequence[int] = ()  # stages with a SelfAttention layer (network.py:304-310, 503-509)
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -204,7 +205,7 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
                              scales[f"{path}.conv.net.1"], 0)
     else:
         w = params[f"{path}.conv.conv.weight"]
-        b = params[f"{path}.conv.conv.bias"]
+        b = params.get(f"{path}.conv.conv.bias")  # (absent: a layer built with bias=False)
         k = w.shape[2]
         pad = (k - 1) // 2 if pad is None else pad
         h = equalized_conv1d(x, w, b, scales[path], pad)
@@ -215,6 +216,19 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
     if drop:
         h = gdrop(h, drop, src)
     return h
+
+
+def self_attention(params, scales, prefix: str, x):
+    """SelfAttention.forward, layers.py:56-64: linear 1x1 convs to query, key and value, key and value max-pooled by
+    4 along time, the softmax taken over the (pooled) key positions, the result of the last 1x1 conv scaled by the
+    scalar gamma and added to the input.  Returns (output, attention map [B, T/4, T])."""
+    lin = dict(act_alpha=-1)
+    query = general_conv(x, params, scales, f"{prefix}.query_conv", **lin)
+    key = F.max_pool1d(general_conv(x, params, scales, f"{prefix}.key_conv", **lin), 4)
+    value = F.max_pool1d(general_conv(x, params, scales, f"{prefix}.value_conv", **lin), 4)
+    attention = torch.softmax(torch.bmm(key.permute(0, 2, 1), query), dim=1)
+    out = general_conv(torch.bmm(value, attention), params, scales, f"{prefix}.final_conv", **lin)
+    return params[f"{prefix}.gamma"] * out + x, attention
 
 
 def linear_interp_upsample(x, p: int):
@@ -372,12 +386,19 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
     def to_rgb(prefix, h):
         return g_to_rgb(params, scales, prefix, h, cfg)
 
+    def attend(layer, h):  # network.py:324-330: before stage ``layer`` grows (never before the last stage, 383-390)
+        if layer in cfg.self_attention_layers:
+            return self_attention(params, scales, f"dummy.{list(cfg.self_attention_layers).index(layer)}", h)[0]
+        return h
+
     h = (pixel_norm(z) if cfg.normalize_latents else z).unsqueeze(2)
     h = gblock("block0", h, first=True)
     if cfg.rgb_generation_mode != "pggan":
         # network.py:332-349, 372-392: every stage's signal, each sum resampled to the next stage's length
         saved = [to_rgb("block0", h)]
         for i in range(depth):
+            if i < depth - 1:
+                h = attend(i, h)
             h = gblock(f"blocks.{i}", resample(h, cfg.scale_down[i], cfg.scale_up[i]))
             saved.append(to_rgb(f"blocks.{i}", h))
         total = saved[0]
@@ -392,7 +413,7 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
     if depth == 0:
         return to_rgb("block0", h)
     for i in range(depth - 1):
-        h = resample(h, cfg.scale_down[i], cfg.scale_up[i])
+        h = resample(attend(i, h), cfg.scale_down[i], cfg.scale_up[i])
         h = gblock(f"blocks.{i}", h)
     h = resample(h, cfg.scale_down[depth - 1], cfg.scale_up[depth - 1])
     ult = to_rgb(f"blocks.{depth - 1}", gblock(f"blocks.{depth - 1}", h))
@@ -434,6 +455,8 @@ def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetC
             if cfg.input_to_all_layers:  # network.py:546-549
                 x_low = resample(x_low, cfg.scale_up[i - 2], cfg.scale_down[i - 2])
                 h = (h + from_rgb(R + 2 - i, x_low)) / 2.0
+        if (i - 2) in cfg.self_attention_layers:  # network.py:550-553
+            h = self_attention(params, scales, f"dummy.{list(cfg.self_attention_layers).index(i - 2)}", h)[0]
     o = general_conv(h, params, scales, "linear", act_alpha=-1)
     return o.mean(dim=2).squeeze(), h
 

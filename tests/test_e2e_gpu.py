@@ -536,7 +536,7 @@ def test_full_step_fixture(dev):
 
 
 def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=True, B=8, shard=None, order=None,
-               jitter=0.0, loss_type="wgan_gp", seen=None, models=None):
+               jitter=0.0, loss_type="wgan_gp", seen=None, models=None, prepare=None):
     """Two training steps at depth 2 with the noise off and fixed mixing factors (so that every
     variant sees the same random inputs).  Returns the weights, Adam's moments and step counts.
     ``parts``: the critic loss can be asked for its independent parts (a graph trainer then runs them as two
@@ -563,6 +563,8 @@ def _two_steps(dev, cls, sync_factory=None, lr=0.002, alphas=(1.0, 1.0), parts=T
     zs = [own(torch.randn(B, 256, generator=gen)).to(dev) for _ in range(12)]
     mix = own(torch.rand(B, 1, 1, generator=gen)).to(dev)
     g, d = config.build_models(9, **(models or {}))  # (``models``: constructor overrides, see config.build_models)
+    if prepare is not None:  # (changes to the freshly built networks, e.g. parameters that start at zero)
+        prepare(g, d)
     g, d = g.to(dev), d.to(dev)
     g.depth = d.depth = depth
     for m in list(g.modules()) + list(d.modules()):

@@ -4,7 +4,8 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
-and the generator loss's random multiplier and feature-matching term.  Every case records one critic and one
+separable layers, deep blocks, self attention (wide and narrow stages), and the generator loss's random multiplier and
+feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
 
@@ -37,6 +38,9 @@ CASES = {
     "deep": dict(shared=dict(deep=True), depth=3, alpha=0.8),
     "g_loss_opts": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=1.0),
     "g_loss_opts_rel": dict(depth=1, alpha=1.0, random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
+    # self attention in both networks; gamma (zero at construction) is set so that the layer takes part
+    "attention": dict(shared=dict(self_attention_layers=[0, 1]), depth=3, alpha=1.0, gamma=0.4),
+    "attention_narrow": dict(shared=dict(self_attention_layers=[3]), depth=5, alpha=1.0, gamma=-0.8),
 }
 
 
@@ -49,6 +53,8 @@ def oracle_config(case):
         kw["act_alpha"] = sh["act_alpha"]
     if "deep" in sh:
         kw["deep"] = sh["deep"]
+    if "self_attention_layers" in sh:
+        kw["self_attention_layers"] = tuple(sh["self_attention_layers"])
     for k in ("rgb_generation_mode", "no_tanh", "normalize_latents"):
         if k in ge:
             kw[k] = ge[k]
@@ -68,18 +74,36 @@ def build_pair(case):
         for k in sa:
             assert torch.equal(sa[k], sb[k]), f"{nm}.{k}: initial weights differ"
         assert M.scales_of(a) == M.scales_of(b), f"{nm}: equalized scales differ"
+    if "gamma" in case:
+        set_gamma(g_ref, d_ref, case["gamma"])
     return g_ref, d_ref
+
+
+def set_gamma(g, d, value):
+    """Every SelfAttention layer's scalar, G's and D's apart so that no two layers share a value."""
+    with torch.no_grad():
+        for net, sign in ((g, 1.0), (d, -1.0)):
+            for j, layer in enumerate(getattr(net, "dummy", [])):
+                layer.gamma.fill_(sign * value * (1.0 + 0.25 * j))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(M.REPO, "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma-separated cases to regenerate; the others are kept from the file")
     args = ap.parse_args()
     torch.set_num_threads(8)
     batch = 8
-    fx = {"model_seed": np.array(cfgmod.RANDOM_SEED), "names": np.array(list(CASES))}
+    path = os.path.join(args.out, "variants.npz")
+    only = [n for n in args.only.split(",") if n]
+    fx = {}
+    if only:
+        fx = {k: v for k, v in np.load(path).items() if not any(k.startswith(n + ".") for n in only)}
+    fx.update({"model_seed": np.array(cfgmod.RANDOM_SEED), "names": np.array(list(CASES))})
     for idx, (name, case) in enumerate(CASES.items()):
         seed = 301 + idx
+        if only and name not in only:
+            continue
 
         def close(a, b):  # (a gradient that cancels exactly in the mathematics is round-off noise in both runs)
             return M.rel(a, b) < 1e-9 or float((a - b).norm()) < 1e-12
@@ -169,7 +193,7 @@ def main():
                         fx[f"{name}.{tag}_noise.{k}"] = np.array(M.rel(grads32[k], v))
         print(f"{name}: depth {depth}, alpha {alpha}, d_loss {float(d_loss):.6f}, g_loss {float(g_loss):.6f}; "
               f"weights identical, oracle matches", flush=True)
-    np.savez_compressed(os.path.join(args.out, "variants.npz"), **fx)
+    np.savez_compressed(path, **fx)
 
 
 if __name__ == "__main__":
