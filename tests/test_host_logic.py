@@ -42,7 +42,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):
-        Discriminator(**{**kw, "self_attention_layers": [1]}, **config.DISCRIMINATOR_KWARGS)
+        Discriminator(**{**kw, "num_classes": 10}, **config.DISCRIMINATOR_KWARGS)
     with pytest.raises(NotImplementedError):
         Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "spectral": True})
 
