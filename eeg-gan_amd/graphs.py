@@ -205,6 +205,7 @@ class _SplitCriticIteration:
 
 def _snapshot(modules, optimizers):
     params = [(p, p.detach().clone()) for m in modules for p in m.parameters()]
+    params += [(b, b.detach().clone()) for m in modules for b in m.buffers()]  # (running statistics of batch norms)
     states = []
     for opt in optimizers:
         for p, st in opt.state.items():
@@ -296,7 +297,9 @@ class GraphedTrainer(Trainer):
         # ready-made fakes (losses.discriminator_loss does).
         d_loss_fn = self.d_loss
         self._fakes_call = self._zall = self._fake = None
-        if self.batch_fakes and self.d_training_repeats > 1 and _accepts(self.d_loss, "fake"):
+        # (a generator with batch norm layers couples the samples of a pass: its fakes are made per iteration)
+        per_sample = not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in self.generator.modules())
+        if self.batch_fakes and per_sample and self.d_training_repeats > 1 and _accepts(self.d_loss, "fake"):
             self._zall = z.repeat(self.d_training_repeats, *([1] * (z.dim() - 1)))
 
             def all_fakes():

@@ -3,8 +3,9 @@
 
 Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
 non-equalized layers and the other initialisers.  Separable layers (a depthwise conv followed
-by a 1x1 conv, layers.py:137-147) and self attention (layers.py:41-64) run too.  Options outside that set
-(spectral norm, conditional batch norm) raise ``NotImplementedError`` at construction: there is no second code path.
+by a 1x1 conv, layers.py:137-147) self attention (layers.py:41-64) and batch norm in the generator's layers, plain or modulated by the latent
+(layers.py:93-134), run too.  Options outside that set (spectral norm, class conditioning) raise
+``NotImplementedError`` at construction: there is no second code path.
 """
 from __future__ import annotations
 
@@ -150,16 +151,62 @@ class MinibatchStddev(nn.Module):
         return ops.minibatch_stddev(x, int(min(per_segment, self.group_size)), _segments)
 
 
-def _unsupported(name):
-    class _Unsupported(nn.Module):
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError(f"{name} is outside the accelerated default configuration")
+class ConditionalBatchNorm(nn.Module):
+    """Batch normalisation over (batch, time) per channel, optionally modulated per sample by the latent (reference
+    layers.py:93-134).  Modes: 'BN' (no conditioning: an affine ``nn.BatchNorm1d``'s arithmetic) and 'SM' (self
+    modulation: a normaliser without affine parameters, then ``out + gamma * out + beta`` with gamma / beta from a
+    two-layer 1x1 network on the latent).  The class-conditional modes ('CBN', 'CSM') are not built.  ``normalizer``
+    is the parameter and running-statistics container (same state-dict keys); training / evaluation follows
+    ``self.training``.  First-order differentiable: the layer belongs to the generator."""
 
-    _Unsupported.__name__ = name
-    return _Unsupported
+    def __init__(self, num_features, num_classes, latent_size, spectral):
+        super().__init__()
+        if num_classes != 0:
+            raise NotImplementedError("ConditionalBatchNorm: the class-conditional modes ('CBN', 'CSM') are not supported")
+        no_cond = latent_size == 0
+        self.num_features = num_features
+        self.normalizer = nn.BatchNorm1d(num_features, affine=no_cond)
+        if no_cond:
+            self.mode = "BN"
+        else:
+            self.embed = nn.Sequential(
+                GeneralConv(latent_size, num_features * 2, kernel_size=1, equalized=False, act_alpha=0.0,
+                            spectral=spectral, bias=True),
+                GeneralConv(num_features * 2, num_features * 2, kernel_size=1, equalized=False, act_alpha=-1,
+                            spectral=spectral, bias=False))
+            self.mode = "SM"
+
+    def modulation(self, z):
+        """(gamma, beta), each [B, num_features], from the latent [B, latent] or [B, latent, 1]; (None, None) in
+        'BN' mode."""
+        if self.mode == "BN":
+            return None, None
+        if z is None:
+            raise ValueError("ConditionalBatchNorm in 'SM' mode needs the latent")
+        z = z.unsqueeze(2) if z.dim() == 2 else z
+        if z.shape[2] != 1:
+            raise NotImplementedError("ConditionalBatchNorm: a latent with a time axis")
+        e = self.embed(z)  # [B, 2 F, 1]
+        n = self.num_features
+        gamma = ops.channel_window(e, None, 0, 0, n, channels=n, length=1).reshape(e.shape[0], n)
+        beta = ops.channel_window(e, None, n, 0, n, channels=n, length=1).reshape(e.shape[0], n)
+        return gamma, beta
+
+    def apply_with(self, c, z, drop, slope):
+        """drop * lrelu_slope(this norm of c): the epilogue GeneralConv asks for (slope 1 and no drop: the norm alone)."""
+        bn = self.normalizer
+        train = self.training or bn.running_mean is None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        gmod, bmod = self.modulation(z)
+        if train and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        return ops.bn_act(c, drop, bn.weight, bn.bias, gmod, bmod, bn.running_mean, bn.running_var, slope, bn.eps,
+                          momentum, train)
+
+    def forward(self, x, y=None, z=None):
+        return self.apply_with(x, z, None, 1.0)
 
 
-ConditionalBatchNorm = _unsupported("ConditionalBatchNorm")
 
 
 class SelfAttention(nn.Module):
@@ -297,14 +344,16 @@ class GeneralConv(nn.Module):
                  act_alpha=0.2, do=0, num_classes=0, act_norm=None, spectral=False, init="kaiming_normal", bias=True,
                  separable=False, stride=1):
         super().__init__()
-        if act_norm == "batch" or act_norm not in (None, "pixel"):
-            raise NotImplementedError("GeneralConv: act_norm other than None/'pixel' is not supported")
+        if act_norm not in (None, "pixel", "batch"):
+            raise NotImplementedError("GeneralConv: act_norm other than None / 'pixel' / 'batch' is not supported")
         pad = (kernel_size - 1) // 2 if pad is None else pad
         conv_class = EqualizedSeparableConv1d if separable else EqualizedConv1d
         self.conv = conv_class(in_channels, out_channels, kernel_size, padding=pad, spectral=spectral,
-                               equalized=equalized, init=init, act_alpha=act_alpha, bias=bias, groups=1, stride=stride)
+                               equalized=equalized, init=init, act_alpha=act_alpha,
+                               bias=bias if act_norm != "batch" else False, groups=1, stride=stride)
         self.separable = bool(separable)
-        self.norm = None
+        # (layers.py:190-192: constructed right after the conv, i.e. its modulation network draws its weights next)
+        self.norm = ConditionalBatchNorm(out_channels, num_classes, z_to_bn_size, spectral) if act_norm == "batch" else None
         self.act_alpha = act_alpha
         self.act_norm = act_norm
         net = []
@@ -339,6 +388,13 @@ class GeneralConv(nn.Module):
             if self.act_alpha >= 0 or self.act_norm is not None or self.drop is not None or kind != "same":
                 raise NotImplementedError("fused tanh epilogue needs a plain linear conv")
             return ops.g_layer(x, w, b, None, s, 0.0, mode="tanh", kind="same", tanh_scale=_tanh_scale, flip=c._flip)
+        if self.act_norm == "batch":
+            # conv without bias -> batch norm (-> modulation by the latent) -> (leaky) ReLU -> GDrop (layers.py:207-213)
+            if kind == "tail":
+                raise NotImplementedError("batch norm after the critic's full-length layer")
+            xin = x.squeeze(2) if kind == "head" else x
+            c_lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
+            return self.norm.apply_with(c_lin, z, self._multipliers(x), slope if self.act_alpha >= 0 else 1.0)
         if self.act_norm == "pixel":
             if self.act_alpha < 0 or kind == "tail":
                 raise NotImplementedError("pixel norm is fused with a (leaky-)ReLU same/head conv only")

@@ -8,7 +8,8 @@ Beside the default configuration these options run on the kernels: ``residual`` 
 (``act_alpha=0``), non-equalized layers and the other initialisers, ``separable`` layers (layers.py:137-147), ``deep`` blocks (four layers through a bottleneck with channel-slice /
 concatenation skips, network.py:157-169, 192-193, 407-418, 432-433) and
 the critic's ``input_to_all_layers``
-(network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+(network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553), and in the
+generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -62,7 +63,7 @@ class GBlock(nn.Module):
     def forward(self, x, y=None, z=None, last=False):
         h = x
         for conv in self.convs:
-            h = conv(h)
+            h = conv(h, y=y, z=z)
         if self.deep:
             h = self.residual(h, x)
         elif self.residual is not None:
@@ -79,11 +80,12 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(not spectral, "spectral norm")
-        _require(num_classes == 0 and not z_to_bn and not split_z and not conv_only, "conditioning/z_to_bn/split_z")
+        _require(num_classes == 0 and not split_z and not conv_only, "conditioning/split_z/conv_only")
+        _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
             raise ValueError("invalid rgb_generation_mode: {}".format(rgb_generation_mode))
-        _require(act_norm in (None, "pixel"), f"act_norm={act_norm!r}")
+        _require(act_norm in (None, "pixel", "batch"), f"act_norm={act_norm!r}")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
         self.progression_scale_up = progression_scale_up
@@ -97,7 +99,7 @@ class Generator(nn.Module):
         self.conv_only = False
         self.initial_kernel_size = initial_kernel_size
         self.normalize_latents = normalize_latents
-        self.z_to_bn = False
+        self.z_to_bn = bool(z_to_bn)
 
         def nf(stage):
             return min(max(int(fmap_base / (2.0 ** stage)), fmap_min), fmap_max)
@@ -109,8 +111,9 @@ class Generator(nn.Module):
         self.y_encoder = None
         block_settings = dict(ch_rgb=num_rgb_channels, k_size=kernel_size, is_residual=residual, deep=deep,
                               no_tanh=no_tanh, per_channel_noise=per_channel_noise, to_rgb_mode=to_rgb_mode)
-        layer_settings = dict(z_to_bn_size=0, equalized=equalized, spectral=spectral, init=init, act_alpha=act_alpha,
-                              do=dropout, num_classes=num_classes, act_norm=act_norm, bias=True, separable=separable)
+        layer_settings = dict(z_to_bn_size=latent_size if z_to_bn else 0, equalized=equalized, spectral=spectral,
+                              init=init, act_alpha=act_alpha, do=dropout, num_classes=num_classes, act_norm=act_norm,
+                              bias=True, separable=separable)
         self.block0 = GBlock(latent_size, nf(1), initial_kernel_size=initial_kernel_size, **block_settings,
                              **layer_settings)
         self.self_attention = dict()  # (network.py:304-310: stage -> layer; registered through ``dummy``)
@@ -152,23 +155,24 @@ class Generator(nn.Module):
         if self.normalize_latents:
             z = pixel_norm(z)
         h = z.unsqueeze(2) if z.dim() == 2 else z
+        zc = h if self.z_to_bn else None  # the (normalised) latent, for the layers' batch norms (network.py:317-322)
         d = self.depth
         maps = {}  # attention maps by stage; the newest stage never gets the layer (network.py:383-390)
         if self.rgb_generation_mode != "pggan":
             saved = []
-            h = self.block0(h)
+            h = self.block0(h, None, zc)
             saved.append(self.block0.to_rgb(h))
             for i in range(d):
-                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None))
+                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None), None, zc)
                 saved.append(self.blocks[i].to_rgb(h))
             return {"x": self._combine_rgbs(saved), "y": None}, maps
         if d == 0:
-            return {"x": self.block0(h, last=True), "y": None}, maps
-        h = self.block0(h)
+            return {"x": self.block0(h, None, zc, last=True), "y": None}, maps
+        h = self.block0(h, None, zc)
         for i in range(d - 1):
-            h = self.blocks[i](self._grow(h, i, maps))
+            h = self.blocks[i](self._grow(h, i, maps), None, zc)
         h = self._grow(h, d - 1)
-        ult = self.blocks[d - 1](h, last=True)
+        ult = self.blocks[d - 1](h, None, zc, last=True)
         if self.alpha == 1.0:
             return {"x": ult, "y": None}, maps
         prev = self.blocks[d - 2] if d > 1 else self.block0

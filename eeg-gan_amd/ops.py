@@ -875,6 +875,7 @@ class _GLayer(Function):
     """One generator layer, first-order differentiable:
          mode 'pn'  : y = drop * pixelnorm(lrelu(bias + conv(x)))      (kind 'same' or 'head')
          mode 'tanh': y = tanh(tanh_scale * (bias + conv(x)))           (to_rgb)
+         mode 'linear': y = bias + conv(x)                               (kind 'same' or 'head'; before a batch norm)
     """
 
     @staticmethod
@@ -886,9 +887,15 @@ class _GLayer(Function):
             B, Cin = x.shape[0], x.shape[1]
             Cout, _, KT = w.shape
             h = torch.empty((B, Cout, KT), device=x.device, dtype=torch.float32)
+            linear = mode == "linear"
             call("eeggan_head_fwd", x.data_ptr(), w.data_ptr(), _p(bias), None, h.data_ptr(), B, Cin, Cout, KT,
-                 float(in_scale), ACT_LRELU, float(slope), _stream())
-            y, d = pixelnorm_drop_fwd_raw(h, drop)
+                 float(in_scale), ACT_NONE if linear else ACT_LRELU, float(slope), _stream())
+            if linear:
+                y = h
+            elif mode == "pn":
+                y, d = pixelnorm_drop_fwd_raw(h, drop)
+            else:
+                raise ValueError(f"head layer in mode {mode}")
         elif mode == "pn":
             fused = conv1d_pixelnorm_raw(x, w, bias, drop, in_scale=in_scale, slope=slope)
             if fused is not None:
@@ -898,8 +905,12 @@ class _GLayer(Function):
                 y, d = pixelnorm_drop_fwd_raw(h, drop)
         elif mode == "tanh":
             y = conv1d_raw(x, w, bias, None, in_scale=in_scale, act=ACT_TANH, act_param=tanh_scale)
+        elif mode == "linear":
+            y = conv1d_raw(x, w, bias, None, in_scale=in_scale)
         else:
             raise ValueError(mode)
+        if mode == "linear" and drop is not None:
+            raise ValueError("a linear layer takes no drop multipliers")
         ctx.save_for_backward(x, w, drop, y, d, bias)
         ctx.cfg = (in_scale, slope, mode, kind, tanh_scale, bias is not None)
         return y
@@ -914,6 +925,8 @@ class _GLayer(Function):
             gc = torch.empty_like(y)
             call("eeggan_tanh_bwd", gy.data_ptr(), y.data_ptr(), gc.data_ptr(), y.numel(), float(tanh_scale),
                  _stream())
+        elif mode == "linear":
+            gc = gy
         else:
             gc = pixelnorm_drop_bwd_raw(gy, y, drop, d, slope)
         gx = gw = gb = None
@@ -943,6 +956,58 @@ class _GLayer(Function):
 
 def g_layer(x, w, bias, drop, in_scale, slope, mode="pn", kind="same", tanh_scale=0.5, flip=None):
     return _GLayer.apply(x, w, bias, drop, float(in_scale), float(slope), mode, kind, float(tanh_scale), flip)
+
+
+class _BNAct(Function):
+    """Batch normalisation with a generator layer's epilogue (first-order differentiable):
+         y = drop * lrelu(modulate(gamma * normalise(c) + beta))
+    ``gamma`` / ``beta`` [C] or None; ``gmod`` / ``bmod`` [B, C] or None (per-sample scale and shift: o + gmod * o +
+    bmod); the module's running statistics are updated in training mode and used in evaluation mode."""
+
+    @staticmethod
+    def forward(ctx, c, drop, gamma, beta, gmod, bmod, run_mean, run_var, slope, eps, momentum, train):
+        c = _chk(c, "batch norm input")
+        B, C, T = c.shape
+        for t, shape, what in ((gamma, (C,), "gamma"), (beta, (C,), "beta"), (gmod, (B, C), "scale modulation"),
+                               (bmod, (B, C), "shift modulation"), (drop, (B, C), "drop"), (run_mean, (C,), "running mean"),
+                               (run_var, (C,), "running variance")):
+            if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous()
+                                  or t.device != c.device):
+                raise RuntimeError(f"batch norm layer: {what} must be a contiguous float32 {shape} tensor on the device")
+        mean = torch.empty((C,), device=c.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(c)
+        call("eeggan_bn_lrelu_drop_fwd", c.data_ptr(), _p(gamma), _p(beta), _p(gmod), _p(bmod), _p(drop), _p(run_mean),
+             _p(run_var), mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), B, C, T, float(eps), float(momentum), float(slope),
+             int(train), _stream())
+        ctx.save_for_backward(drop, y, c, mean, rstd, gamma, beta, gmod)
+        ctx.cfg = (slope, train)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        drop, y, c, mean, rstd, gamma, beta, gmod = ctx.saved_tensors
+        slope, train = ctx.cfg
+        gy = _chk(gy, "batch norm grad")
+        B, C, T = c.shape
+        gc = torch.empty_like(c)
+        g_gamma = torch.empty((C,), device=c.device, dtype=torch.float32)
+        g_beta = torch.empty_like(g_gamma)
+        g_gmod = g_bmod = None
+        if gmod is not None:
+            g_gmod = torch.empty((B, C), device=c.device, dtype=torch.float32)
+            g_bmod = torch.empty_like(g_gmod)
+        call("eeggan_bn_lrelu_drop_bwd", gy.data_ptr(), y.data_ptr(), c.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma),
+             _p(beta), _p(gmod), _p(drop), gc.data_ptr(), g_gamma.data_ptr(), g_beta.data_ptr(), _p(g_gmod), _p(g_bmod), B, C, T,
+             float(slope), int(train), _stream())
+        return (gc, None, g_gamma if gamma is not None else None, g_beta if beta is not None else None, g_gmod, g_bmod,
+                None, None, None, None, None, None)
+
+
+def bn_act(c, drop, gamma, beta, gmod, bmod, run_mean, run_var, slope, eps, momentum, train):
+    return _BNAct.apply(c, drop, gamma, beta, gmod, bmod, run_mean, run_var, float(slope), float(eps), float(momentum),
+                        bool(train))
 
 
 class _ScaledTanh(Function):

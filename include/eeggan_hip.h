@@ -284,6 +284,25 @@ int eeggan_grad_penalty_bwd(const float* gl, const float* g, const float* norms,
 int eeggan_feature_match_fwd(const float* real, const float* fake, float* diff, float* loss, int B, int F,
                              void* stream);
 int eeggan_feature_match_bwd(const float* gl, const float* diff, float* g_fake, int B, int F, void* stream);
+/* ---- batch normalisation inside a generator layer (act_norm = 'batch': ConditionalBatchNorm, layers.py:93-134,
+ * placed between conv and activation by GeneralConv, layers.py:190-213).  c, y [B, C, T] float32:
+ *   n = (c - mean_ch) rstd_ch,  statistics over (batch, time), biased variance, eps inside the root;
+ *   o = gamma_ch n + beta_ch when gamma / beta are given ('BN' mode), else n;
+ *   o = o + gmod[b,ch] o + bmod[b,ch] when gmod / bmod [B, C] are given (self modulation, layers.py:129-134);
+ *   y = drop[b,ch] lrelu_slope(o)     (drop NULL: 1; slope 1: no activation).
+ * train != 0: mean / rstd [C] are computed and written, and run_mean / run_var (NULL: none) are updated like
+ * nn.BatchNorm1d (momentum, unbiased variance); train == 0: mean / rstd are taken from run_mean / run_var. */
+int eeggan_bn_lrelu_drop_fwd(const float* c, const float* gamma, const float* beta, const float* gmod, const float* bmod,
+                             const float* drop, float* run_mean, float* run_var, float* mean, float* rstd, float* y, int B,
+                             int C, int T, float eps, float momentum, float slope, int train, void* stream);
+/* Backward of the above given gy = d loss / d y: gc = d loss / d c; g_gamma / g_beta [C] (always written: the channel
+ * sums the input gradient needs; the affine parameters' gradients in 'BN' mode); g_gmod / g_bmod [B, C] with the
+ * modulation.  train == 0: the statistics are constants. */
+int eeggan_bn_lrelu_drop_bwd(const float* gy, const float* y, const float* c, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* gmod, const float* drop, float* gc,
+                             float* g_gamma, float* g_beta, float* g_gmod, float* g_bmod, int B, int C, int T, float slope,
+                             int train, void* stream);
+
 /* ---- self attention (SelfAttention, layers.py:41-64): out = gamma * Wf (value P) + x with
  * P = softmax over dim 1 of key^T query, key / value max-pooled by 4 along time.  The 1x1 convs are eeggan_conv1d;
  * the rest is made of the entry points below (float32 tensors). ------------------------------------------------ */

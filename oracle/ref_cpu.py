@@ -60,6 +60,8 @@ class NetConfig:
     input_to_all_layers: bool = False      # the critic sees the down-sampled input at every stage
     deep: bool = False                     # blocks of four layers through a bottleneck, with slice / concatenation skips
     self_attention_layers: Sequence[int] = ()  # stages with a SelfAttention layer (network.py:304-310, 503-509)
+    g_act_norm: Optional[str] = "pixel"    # the generator layers' norm: 'pixel' | 'batch' | None (network.py:229, 257)
+    z_to_bn: bool = False                  # batch norms modulated by the latent (network.py:253, 299, 317-322)
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -190,8 +192,24 @@ def gdrop(x, strength: float, src: DropSource):
     return x * torch.from_numpy(r).to(x.dtype)
 
 
+def conditional_batch_norm(x, params, scales, prefix: str, z=None):
+    """ConditionalBatchNorm.forward in training mode, layers.py:117-134: statistics of the batch over (batch, time);
+    'BN' mode (affine normaliser) when the layer has no modulation network, else 'SM': a normaliser without affine
+    parameters, then out + gamma * out + beta with (gamma, beta) = the two halves of a two-layer 1x1 network (ReLU in
+    between, layers.py:107-111) on the latent [B, latent, 1], repeated over time."""
+    out = F.batch_norm(x, None, None, params.get(f"{prefix}.normalizer.weight"), params.get(f"{prefix}.normalizer.bias"),
+                       training=True, eps=1e-5)
+    if f"{prefix}.embed.0.conv.conv.weight" not in params:
+        return out
+    e = general_conv(z, params, scales, f"{prefix}.embed.0", act_alpha=0.0)
+    e = general_conv(e, params, scales, f"{prefix}.embed.1", act_alpha=-1)
+    e = resample(e, e.shape[2], out.shape[2])
+    gamma, beta = e.chunk(2, dim=1)
+    return out + gamma * out + beta
+
+
 def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None, drop=0.0,
-                 src: Optional[DropSource] = None):
+                 src: Optional[DropSource] = None, z=None):
     """layers.py:207-213 for the default options: conv -> LeakyReLU ->
     (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
     if f"{path}.conv.net.0.conv.weight" in params:
@@ -209,6 +227,8 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
         k = w.shape[2]
         pad = (k - 1) // 2 if pad is None else pad
         h = equalized_conv1d(x, w, b, scales[path], pad)
+    if norm == "batch":  # layers.py:211-212: between conv and activation
+        h = conditional_batch_norm(h, params, scales, f"{path}.norm", z)
     if act_alpha >= 0:
         h = leaky_relu(h, act_alpha) if act_alpha > 0 else F.relu(h)
     if norm == "pixel":
@@ -310,11 +330,11 @@ def minibatch_stddev(x, group_size: int = 4, window: int = 32):
 
 # --------------------------------------------------------------------------- networks
 def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", first: bool = False,
-            last: bool = False):
+            last: bool = False, z=None):
     """GBlock.forward, network.py:206-218 (no residual, not deep): two GeneralConvs with pixel norm and
     GDrop, the first one with the full-length kernel and pad = k-1 in the first block (network.py:157-159);
     ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
-    ls = dict(act_alpha=cfg.act_alpha, norm="pixel", drop=cfg.g_dropout, src=src)
+    ls = dict(act_alpha=cfg.act_alpha, norm=cfg.g_act_norm, drop=cfg.g_dropout, src=src, z=z)
     x = h
     h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
     h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
@@ -381,7 +401,7 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
     src = src or DropSource("off")
 
     def gblock(prefix, h, first=False):
-        return g_block(params, scales, prefix, h, cfg, src, first=first)
+        return g_block(params, scales, prefix, h, cfg, src, first=first, z=zc)
 
     def to_rgb(prefix, h):
         return g_to_rgb(params, scales, prefix, h, cfg)
@@ -392,6 +412,7 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
         return h
 
     h = (pixel_norm(z) if cfg.normalize_latents else z).unsqueeze(2)
+    zc = h if cfg.z_to_bn else None  # network.py:317-322: the layers' batch norms see the (normalised) latent
     h = gblock("block0", h, first=True)
     if cfg.rgb_generation_mode != "pggan":
         # network.py:332-349, 372-392: every stage's signal, each sum resampled to the next stage's length

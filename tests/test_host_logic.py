@@ -40,7 +40,9 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
     with pytest.raises(NotImplementedError):
-        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "act_norm": "batch"})
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "split_z": True})
+    with pytest.raises(NotImplementedError):
+        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):
         Discriminator(**{**kw, "num_classes": 10}, **config.DISCRIMINATOR_KWARGS)
     with pytest.raises(NotImplementedError):

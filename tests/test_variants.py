@@ -1,7 +1,8 @@
 """Network and loss options beside the defaults: residual blocks (network.py:195-199, 217-218, 435-438, 447-448), the
 generator's 'residual' / 'mean' signal modes (332-349), the critic's input at every stage (533-549), plain layers
 (ReLU, no equalization, xavier init, to_rgb without tanh, latents not normalised, no MinibatchStddev), separable
-layers, deep blocks, self attention (layers.py:41-64) and the generator loss's random multiplier and feature-matching
+layers, deep blocks, self attention (layers.py:41-64), batch norm in the generator plain and modulated by the latent
+(layers.py:93-134) and the generator loss's random multiplier and feature-matching
 term (losses.py:46, 62-70).
 
 Fixture ``variants.npz`` (``tools/make_golden_variants.py``): per case one critic and one generator loss evaluation
@@ -31,6 +32,8 @@ CASES = {
     "g_loss_opts_rel": dict(random_multiply=True, feature_matching_lambda=0.5, loss_type="rasgan"),
     "attention": dict(shared=dict(self_attention_layers=[0, 1]), gamma=0.4),
     "attention_narrow": dict(shared=dict(self_attention_layers=[3]), gamma=-0.8),
+    "batch_norm": dict(generator=dict(act_norm="batch")),
+    "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True)),
 }
 
 
@@ -54,9 +57,11 @@ def _oracle_config(case):
     from oracle import ref_cpu as O
     kw = {}
     for src, keys in ((case.get("shared", {}), ("residual", "act_alpha", "deep", "self_attention_layers")),
-                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents")),
+                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn")),
                       (case.get("discriminator", {}), ("input_to_all_layers", "group_size"))):
         kw.update({k: src[k] for k in keys if k in src})
+    if "act_norm" in case.get("generator", {}):
+        kw["g_act_norm"] = case["generator"]["act_norm"]
     return O.NetConfig(**kw)
 
 
@@ -93,6 +98,8 @@ def test_oracle_matches_reference(name):
     loss, _ = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
     assert abs(float(loss) - float(c["d_loss"])) < 1e-9 * max(1.0, abs(float(c["d_loss"])))
     for k, gr in zip(dp.keys(), torch.autograd.grad(loss, list(dp.values()), allow_unused=True)):
+        if gr is None and k not in dict(d.named_parameters()):
+            continue  # (a buffer of the module: running statistics)
         assert (gr is None) == (f"d_none.{k}" in c) and (gr is None or _close(subsample(gr), c[f"d_sub.{k}"])), k
     np.random.seed(seed + 2)
     random.seed(seed + 3)
@@ -102,13 +109,15 @@ def test_oracle_matches_reference(name):
                            feature_matching_lambda=case.get("feature_matching_lambda", 0.0))
     assert abs(float(loss) - float(c["g_loss"])) < 1e-9 * max(1.0, abs(float(c["g_loss"])))
     for k, gr in zip(gp.keys(), torch.autograd.grad(loss, list(gp.values()), allow_unused=True)):
+        if gr is None and k not in dict(g.named_parameters()):
+            continue
         assert (gr is None) == (f"g_none.{k}" in c) and (gr is None or _close(subsample(gr), c[f"g_sub.{k}"])), k
 
 
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
     for kw in (dict(generator=dict(per_channel_noise=True)), dict(generator=dict(spectral=True)),
-               dict(generator=dict(act_norm="batch")), dict(generator=dict(to_rgb_mode="sagan"))):
+               dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10)), dict(generator=dict(to_rgb_mode="sagan"))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
@@ -206,6 +215,54 @@ def test_attention_layer_against_torch(dev):
         (gd,) = torch.autograd.grad(want, xd, cot.double())
         (gg,) = torch.autograd.grad(got, xg, cot.to(dev))
         assert rel(gg, gd) < 1e-5, rel(gg, gd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 64, 480), (5, 37, 50), (4, 256, 32)])
+def test_batch_norm_layer_against_torch(dev, shape):
+    """ConditionalBatchNorm in 'BN' mode against nn.BatchNorm1d in fp64: training-mode values, gradients of input and
+    affine parameters, running statistics after two calls, and evaluation mode; then the fused epilogue
+    (modulation, LeakyReLU, multipliers) against the same arithmetic written out."""
+    import torch.nn.functional as F
+    from eeggan_amd import ops
+    from eeggan_amd.layers import ConditionalBatchNorm
+    B, C, T = shape
+    gen = torch.Generator().manual_seed(C)
+    x1, x2 = (torch.randn(B, C, T, generator=gen) * 1.7 + 0.4 for _ in range(2))
+    cot = torch.randn(B, C, T, generator=gen)
+    ref = torch.nn.BatchNorm1d(C).double()
+    mine = ConditionalBatchNorm(C, 0, 0, False).to(dev)
+    with torch.no_grad():
+        w, b = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+        ref.weight.copy_(w), ref.bias.copy_(b)
+        mine.normalizer.weight.copy_(w), mine.normalizer.bias.copy_(b)
+    xd, xg = x1.double().requires_grad_(True), x1.to(dev).requires_grad_(True)
+    yd, yg = ref(xd), mine(xg)
+    assert rel(yg, yd) < 1e-5
+    want = torch.autograd.grad(yd, [xd, ref.weight, ref.bias], cot.double())
+    got = torch.autograd.grad(yg, [xg, mine.normalizer.weight, mine.normalizer.bias], cot.to(dev))
+    for a, e, what in zip(got, want, ("input", "weight", "bias")):
+        assert rel(a, e) < 2e-5, (what, rel(a, e))
+    ref(x2.double()), mine(x2.to(dev))
+    assert rel(mine.normalizer.running_mean, ref.running_mean) < 1e-5 and rel(mine.normalizer.running_var, ref.running_var) < 1e-5
+    assert int(mine.normalizer.num_batches_tracked) == 2
+    ref.eval(), mine.eval()
+    xd, xg = x1.double().requires_grad_(True), x1.to(dev).requires_grad_(True)
+    yd, yg = ref(xd), mine(xg)
+    assert rel(yg, yd) < 1e-5
+    assert rel(torch.autograd.grad(yg, xg, cot.to(dev))[0], torch.autograd.grad(yd, xd, cot.double())[0]) < 1e-5
+    # the fused epilogue with per-sample modulation
+    gm, bm, dr = torch.randn(B, C, generator=gen) * 0.3, torch.randn(B, C, generator=gen), torch.rand(B, C, generator=gen) + 0.5
+    ins_d = [t.double().requires_grad_(True) for t in (x1, gm, bm)]
+    n = F.batch_norm(ins_d[0], None, None, None, None, training=True, eps=1e-5)
+    o = n + ins_d[1][:, :, None] * n + ins_d[2][:, :, None]
+    yd = F.leaky_relu(o, 0.2) * dr.double()[:, :, None]
+    ins_g = [t.to(dev).requires_grad_(True) for t in (x1, gm, bm)]
+    yg = ops.bn_act(ins_g[0], dr.to(dev), None, None, ins_g[1], ins_g[2], None, None, 0.2, 1e-5, 0.1, True)
+    assert rel(yg, yd) < 1e-5
+    for a, e, what in zip(torch.autograd.grad(yg, ins_g, cot.to(dev)), torch.autograd.grad(yd, ins_d, cot.double()),
+                          ("input", "scale modulation", "shift modulation")):
+        assert rel(a, e) < 2e-5, (what, rel(a, e))
 
 
 @pytest.mark.gpu
@@ -332,5 +389,24 @@ def test_graph_trainer_with_attention(dev):
         base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
         graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
         E._same_trajectory(base, graphed, "graph replay, self attention", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+def test_graph_trainer_with_batch_norm(dev):
+    """A generator with batch norm layers modulated by the latent under the graph trainer: the fakes are made per
+    critic iteration (batch statistics couple the samples of a pass, so one pass over all iterations' latents would
+    change them), running statistics move with the replays, and the trajectory is the eager trainer's."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models=dict(generator=dict(act_norm="batch", z_to_bn=True)))
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        E._same_trajectory(base, graphed, "graph replay, batch norm", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")

@@ -4,7 +4,8 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
-separable layers, deep blocks, self attention (wide and narrow stages), and the generator loss's random multiplier and
+separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
+modulated by the latent), and the generator loss's random multiplier and
 feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
@@ -41,6 +42,9 @@ CASES = {
     # self attention in both networks; gamma (zero at construction) is set so that the layer takes part
     "attention": dict(shared=dict(self_attention_layers=[0, 1]), depth=3, alpha=1.0, gamma=0.4),
     "attention_narrow": dict(shared=dict(self_attention_layers=[3]), depth=5, alpha=1.0, gamma=-0.8),
+    # batch norm in the generator's layers: plain (affine), and modulated by the latent
+    "batch_norm": dict(generator=dict(act_norm="batch"), depth=3, alpha=0.6),
+    "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True), depth=2, alpha=1.0),
 }
 
 
@@ -55,9 +59,11 @@ def oracle_config(case):
         kw["deep"] = sh["deep"]
     if "self_attention_layers" in sh:
         kw["self_attention_layers"] = tuple(sh["self_attention_layers"])
-    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents"):
+    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn"):
         if k in ge:
             kw[k] = ge[k]
+    if "act_norm" in ge:
+        kw["g_act_norm"] = ge["act_norm"]
     for k in ("input_to_all_layers", "group_size"):
         if k in di:
             kw[k] = di[k]
