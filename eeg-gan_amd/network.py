@@ -9,7 +9,8 @@ Beside the default configuration these options run on the kernels: ``residual`` 
 concatenation skips, network.py:157-169, 192-193, 407-418, 432-433) and
 the critic's ``input_to_all_layers``
 (network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553), and in the
-generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322)
+and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -80,7 +81,7 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(not spectral, "spectral norm")
-        _require(num_classes == 0 and not split_z and not conv_only, "conditioning/split_z/conv_only")
+        _require(num_classes == 0 and not conv_only, "conditioning/conv_only")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
@@ -94,7 +95,7 @@ class Generator(nn.Module):
         self.alpha = 1.0
         # optional one-element device tensor mirroring alpha (kept current by graphs.GraphedTrainer)
         self.alpha_dev = None
-        self.split_z = False
+        self.split_z = bool(split_z) and not deep  # (network.py:270-272)
         self.z_distribution = z_distribution
         self.conv_only = False
         self.initial_kernel_size = initial_kernel_size
@@ -107,6 +108,8 @@ class Generator(nn.Module):
         if latent_size is None:
             latent_size = nf(0)
         self.input_latent_size = latent_size
+        if self.split_z:  # network.py:294-295: one share of the latent per block plus one for the first layer's input
+            latent_size //= stages + 2
         self.latent_size = latent_size
         self.y_encoder = None
         block_settings = dict(ch_rgb=num_rgb_channels, k_size=kernel_size, is_residual=residual, deep=deep,
@@ -155,24 +158,32 @@ class Generator(nn.Module):
         if self.normalize_latents:
             z = pixel_norm(z)
         h = z.unsqueeze(2) if z.dim() == 2 else z
-        zc = h if self.z_to_bn else None  # the (normalised) latent, for the layers' batch norms (network.py:317-322)
+        if self.split_z:
+            # network.py:317-322, 368-371: the first share feeds the first layer, share 2 + l the batch norms of
+            # block l (block0: l = -1); without z_to_bn the other shares are unused
+            share, whole = self.latent_size, h
+            h = whole[:, :share].contiguous()
+            zs = (lambda l: whole[:, (2 + l) * share:(3 + l) * share].contiguous()) if self.z_to_bn else (lambda l: None)
+        else:
+            zc = h if self.z_to_bn else None  # the (normalised) latent, for the layers' batch norms
+            zs = lambda l: zc  # noqa: E731
         d = self.depth
         maps = {}  # attention maps by stage; the newest stage never gets the layer (network.py:383-390)
         if self.rgb_generation_mode != "pggan":
             saved = []
-            h = self.block0(h, None, zc)
+            h = self.block0(h, None, zs(-1))
             saved.append(self.block0.to_rgb(h))
             for i in range(d):
-                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None), None, zc)
+                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None), None, zs(i))
                 saved.append(self.blocks[i].to_rgb(h))
             return {"x": self._combine_rgbs(saved), "y": None}, maps
         if d == 0:
-            return {"x": self.block0(h, None, zc, last=True), "y": None}, maps
-        h = self.block0(h, None, zc)
+            return {"x": self.block0(h, None, zs(-1), last=True), "y": None}, maps
+        h = self.block0(h, None, zs(-1))
         for i in range(d - 1):
-            h = self.blocks[i](self._grow(h, i, maps), None, zc)
+            h = self.blocks[i](self._grow(h, i, maps), None, zs(i))
         h = self._grow(h, d - 1)
-        ult = self.blocks[d - 1](h, None, zc, last=True)
+        ult = self.blocks[d - 1](h, None, zs(d - 1), last=True)
         if self.alpha == 1.0:
             return {"x": ult, "y": None}, maps
         prev = self.blocks[d - 2] if d > 1 else self.block0

@@ -62,6 +62,7 @@ class NetConfig:
     self_attention_layers: Sequence[int] = ()  # stages with a SelfAttention layer (network.py:304-310, 503-509)
     g_act_norm: Optional[str] = "pixel"    # the generator layers' norm: 'pixel' | 'batch' | None (network.py:229, 257)
     z_to_bn: bool = False                  # batch norms modulated by the latent (network.py:253, 299, 317-322)
+    split_z: bool = False                  # one share of the latent per block (network.py:294-295, 317-322, 368-371)
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -401,7 +402,8 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
     src = src or DropSource("off")
 
     def gblock(prefix, h, first=False):
-        return g_block(params, scales, prefix, h, cfg, src, first=first, z=zc)
+        layer = -1 if first else int(prefix.split(".")[1])
+        return g_block(params, scales, prefix, h, cfg, src, first=first, z=z_of(layer))
 
     def to_rgb(prefix, h):
         return g_to_rgb(params, scales, prefix, h, cfg)
@@ -412,7 +414,16 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
         return h
 
     h = (pixel_norm(z) if cfg.normalize_latents else z).unsqueeze(2)
-    zc = h if cfg.z_to_bn else None  # network.py:317-322: the layers' batch norms see the (normalised) latent
+    whole = h
+    if cfg.split_z:  # network.py:294-295, 368-371: the first share is the first layer's input
+        share = cfg.latent_size // (cfg.num_stages + 2)
+        h = whole[:, :share]
+
+    def z_of(layer):  # network.py:317-322: what the batch norms of block ``layer`` see (block0: -1)
+        if not cfg.z_to_bn:
+            return None
+        return whole[:, (2 + layer) * share:(3 + layer) * share] if cfg.split_z else whole
+
     h = gblock("block0", h, first=True)
     if cfg.rgb_generation_mode != "pggan":
         # network.py:332-349, 372-392: every stage's signal, each sum resampled to the next stage's length

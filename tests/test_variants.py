@@ -34,6 +34,7 @@ CASES = {
     "attention_narrow": dict(shared=dict(self_attention_layers=[3]), gamma=-0.8),
     "batch_norm": dict(generator=dict(act_norm="batch")),
     "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True)),
+    "split_z": dict(generator=dict(act_norm="batch", z_to_bn=True, split_z=True)),
 }
 
 
@@ -57,7 +58,7 @@ def _oracle_config(case):
     from oracle import ref_cpu as O
     kw = {}
     for src, keys in ((case.get("shared", {}), ("residual", "act_alpha", "deep", "self_attention_layers")),
-                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn")),
+                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z")),
                       (case.get("discriminator", {}), ("input_to_all_layers", "group_size"))):
         kw.update({k: src[k] for k in keys if k in src})
     if "act_norm" in case.get("generator", {}):

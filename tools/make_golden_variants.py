@@ -45,6 +45,7 @@ CASES = {
     # batch norm in the generator's layers: plain (affine), and modulated by the latent
     "batch_norm": dict(generator=dict(act_norm="batch"), depth=3, alpha=0.6),
     "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True), depth=2, alpha=1.0),
+    "split_z": dict(generator=dict(act_norm="batch", z_to_bn=True, split_z=True), depth=2, alpha=0.5),
 }
 
 
@@ -59,7 +60,7 @@ def oracle_config(case):
         kw["deep"] = sh["deep"]
     if "self_attention_layers" in sh:
         kw["self_attention_layers"] = tuple(sh["self_attention_layers"])
-    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn"):
+    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z"):
         if k in ge:
             kw[k] = ge[k]
     if "act_norm" in ge:
