@@ -26,6 +26,11 @@ namespace eeggan {
 namespace {
 
 constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment)
+constexpr int WGRAD_LDH = 88;  // halfwords per LDS row of the weight gradient's bfloat16-native tiles (see wgrad_body)
+// LDS of that form: two buffers of two tiles, or the eight waves' closing exchange of sums, whichever is larger
+constexpr size_t WGRAD_BFN_LDS = (size_t)4 * (3 * 16 + 1) * 64 * sizeof(float) > (size_t)2 * 2 * 64 * WGRAD_LDH * 2
+                                     ? (size_t)4 * (3 * 16 + 1) * 64 * sizeof(float)
+                                     : (size_t)2 * 2 * 64 * WGRAD_LDH * 2;
 
 // Split products: an fp32 operand as the sum of three bf16 pieces (v = p1 + p2 + p3 up to 2^-24 |v|), see conv_ws.hip
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
@@ -1076,6 +1081,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     constexpr int NTW = 2;
     constexpr int LD = NTW * SUB + 4;  // 84: (LD/4) odd -> conflict-free b128 row-indexed reads
     constexpr int BUF = 2 * 64 * LD;   // floats per LDS buffer (gy tile + x tile)
+    // BFN (both tensors bfloat16, predicate-free form): the LDS tiles hold the stored bfloat16 values themselves, in
+    // rows of LDH halfwords (176 bytes: (176 / 16) odd, conflict-free 16-byte row-indexed reads); a subtile takes 40
+    // halfwords of a row from halfword 8 on (left halo at 7, right halo at 40).  A lane's eight time steps of a row
+    // are then ONE 16-byte LDS read that already is the matrix operand: no conversion in the loop, half the LDS
+    // traffic, and 45 KB of tiles instead of 86, so that two workgroups share a CU and twice the loads are in flight
+    // (the kernel is bound by memory latency: one workgroup per CU keeps 24 KB per CU in flight).
+    constexpr bool BFN = FULL && SPLIT == 1 && XBF && GBF;
+    constexpr int LDH = WGRAD_LDH;
+    constexpr int BUFH = 2 * 64 * LDH;  // halfwords per LDS buffer in that form
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -1106,6 +1120,40 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     if (it1 > total_pairs) it1 = total_pairs;
 
     auto mfma_block = [&](const float* Gs, const float* Xs) {
+        if constexpr (BFN) {
+            const unsigned short* Gr = reinterpret_cast<const unsigned short*>(Gs) + (cot * 32 + l31) * LDH + 8 + 8 * h + part * 40;
+            const unsigned short* Xr = reinterpret_cast<const unsigned short*>(Xs) + (cit * 32 + l31) * LDH + 8 + 8 * h + part * 40;
+            u32x4s gw[2], xw[2];
+            unsigned xl[2], xh[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                gw[hf] = *reinterpret_cast<const u32x4s*>(Gr + 16 * hf);
+                xw[hf] = *reinterpret_cast<const u32x4s*>(Xr + 16 * hf);
+                xl[hf] = Xr[16 * hf - 1];
+                xh[hf] = Xr[16 * hf + 8];
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                // the stored words are samples (1,2) (3,4) (5,6) (7,8) of the ten around this lane's eight time steps:
+                // the middle tap's operand as they are, the outer taps re-cut across the word borders
+                u32x4s t0, t2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    t0[i] = __builtin_amdgcn_alignbit(xw[hf][i], i ? xw[hf][i ? i - 1 : 0] : xl[hf] << 16, 16);
+                    t2[i] = __builtin_amdgcn_alignbit(i < 3 ? xw[hf][i < 3 ? i + 1 : 3] : xh[hf], xw[hf][i], 16);
+                }
+                const bf16x8s G1 = __builtin_bit_cast(bf16x8s, gw[hf]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, __builtin_bit_cast(bf16x8s, t0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, __builtin_bit_cast(bf16x8s, xw[hf]), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(G1, __builtin_bit_cast(bf16x8s, t2), acc[2], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        bsum += __builtin_bit_cast(float, gw[hf][i] << 16) + __builtin_bit_cast(float, gw[hf][i] & 0xffff0000u);
+                }
+            }
+            return;
+        }
         if constexpr (SPLIT) {
             const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h + part * SUB;  // (this wave's subtile of the pair)
             const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h + part * SUB;
@@ -1280,6 +1328,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             }
         };
         auto commit = [&](float* Gs, float* Xs) {
+            if constexpr (BFN) {
+                unsigned short* Gh = reinterpret_cast<unsigned short*>(Gs);
+                unsigned short* Xh = reinterpret_cast<unsigned short*>(Xs);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    u32x2 gq = gv[i], xq = xv[i];
+                    if (a.mask_y) {  // the masked gradient, rounded to bfloat16 once (it is a matrix operand)
+                        f32x4 g = widen(gv[i]);
+                        const float d = a.mask_drop ? md[i] : 1.f;
+                        const f32x4 my = widen(mv[i]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g[e] *= my[e] > 0.f ? d : d * a.mask_slope;
+                        gq[0] = pack_bf16s(g[0], g[1]);
+                        gq[1] = pack_bf16s(g[2], g[3]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        gq[e] = ok ? gq[e] : 0u;
+                        xq[e] = ok ? xq[e] : 0u;
+                    }
+                    const int o = (r0 + RSTEP * i) * LDH + n * 40 + 8 + 4 * q;
+                    *reinterpret_cast<u32x2*>(Gh + o) = gq;
+                    *reinterpret_cast<u32x2*>(Xh + o) = xq;
+                }
+                if (hr < 64) Xh[hr * LDH + hn * 40 + (hs ? 40 : 7)] = hok ? hv : (unsigned short)0;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 f32x4 g = widen(gv[i]), x = widen(xv[i]);
@@ -1301,24 +1376,26 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         };
 
         EEGGAN_STAMP(0, 6);
+        // (floats per buffer and per tile; the bfloat16-native form counts its halfwords in floats)
+        constexpr int BUFF = BFN ? BUFH / 2 : BUF, TILEF = BFN ? 64 * LDH / 2 : 64 * LD;
         if (it0 < it1) {
             issue(it0);
-            commit(smem, smem + 64 * LD);
+            commit(smem, smem + TILEF);
         }
         __syncthreads();
         EEGGAN_STAMP(0, 7);
         for (int it = it0; it < it1; ++it) {
             const bool more = it + 1 < it1;
-            float* cur = smem + ((it - it0) & 1) * BUF;
-            float* nxt = smem + ((it - it0 + 1) & 1) * BUF;
+            float* cur = smem + ((it - it0) & 1) * BUFF;
+            float* nxt = smem + ((it - it0 + 1) & 1) * BUFF;
             EEGGAN_STAMP(it - it0, 0);
             if (more) issue(it + 1);
             __builtin_amdgcn_sched_barrier(0);
             EEGGAN_STAMP(it - it0, 1);
-            mfma_block(cur, cur + 64 * LD);
+            mfma_block(cur, cur + TILEF);
             EEGGAN_STAMP(it - it0, 2);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) commit(nxt, nxt + 64 * LD);
+            if (more) commit(nxt, nxt + TILEF);
             EEGGAN_STAMP(it - it0, 3);
             __syncthreads();
             EEGGAN_STAMP(it - it0, 4);
@@ -1399,8 +1476,9 @@ struct WgradPack {
     int n;
 };
 
+// (the bfloat16-native form asks for registers that let two workgroups of eight waves share a CU: four waves per SIMD)
 template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
-__global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_multi_kernel(WgradPack pk) {
+__global__ __launch_bounds__(SPLIT ? 512 : 256, (FULL && SPLIT == 1 && XBF && GBF) ? 4 : 1) void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
     while (k + 1 < pk.n && blk >= pk.first[k + 1]) ++k;
@@ -1455,20 +1533,27 @@ struct WgradPlan {
     size_t slab_elems, bytes;
 };
 
-WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K) {
+// ``per_cu``: workgroups the kernel variant places on one CU (2 for the bfloat16-native form).  The workspace is
+// always sized for 2, so that one size serves every variant of a layer.
+WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K, int per_cu = 1) {
     WgradPlan p;
     p.nco = (Cout + 63) / 64;
     p.nci = (Cin + 63) / 64;
     p.regions = p.nco * p.nci;
     const int ST = (T + 31) / 32;
     const int pairs = (B * ST + 1) / 2;
-    int want = (256 + p.regions - 1) / p.regions;  // ~1 workgroup per CU over the whole grid
-    if (want > pairs) want = pairs;
-    if (want < 1) want = 1;
-    p.iters = (pairs + want - 1) / want;
-    p.nsplit = (pairs + p.iters - 1) / p.iters;
+    auto splits = [&](int wgs, int* iters) {
+        int want = (wgs + p.regions - 1) / p.regions;  // ~wgs workgroups over the whole grid
+        if (want > pairs) want = pairs;
+        if (want < 1) want = 1;
+        *iters = (pairs + want - 1) / want;
+        return (pairs + *iters - 1) / *iters;
+    };
+    p.nsplit = splits(256 * per_cu, &p.iters);
+    int unused;
+    const int most = splits(256 * 2, &unused);
     p.slab_elems = (size_t)Cout * Cin * K;
-    p.bytes = ((size_t)p.nsplit * (p.slab_elems + Cout) * sizeof(float) + 255) & ~(size_t)255;
+    p.bytes = ((size_t)(most > p.nsplit ? most : p.nsplit) * (p.slab_elems + Cout) * sizeof(float) + 255) & ~(size_t)255;
     return p;
 }
 
@@ -1820,7 +1905,6 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     EEGGAN_REQUIRE(jobs && jobs_w && jobs_b && njobs > 0, "conv1d_wgrad_partial_multi: bad table");
     hipStream_t st = as_stream(stream);
     constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
-    const int cus = num_cus();
     // kernel variant per job: (0 = K 3 without predicates, 1 = K 3 generic, 2 = K 1) * 4 + storage types of x and gy
     auto variant = [](const eeggan_wgrad_job& j) {
         const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
@@ -1844,13 +1928,15 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     for (int v = 0; v < 12; ++v) {
         int idx[WG_MAXJ];
         int n = 0;
+        const int per_cu = v == 3 ? 2 : 1;  // (the bfloat16-native form: two workgroups per CU)
+        const int cus = per_cu * num_cus();
         auto flush = [&]() -> int {
             if (n == 0) return 0;
             WgradPlan plan[WG_MAXJ];
             long long pairs[WG_MAXJ], units = 0, longest = 1;
             for (int k = 0; k < n; ++k) {
                 const eeggan_wgrad_job& j = jobs[idx[k]];
-                plan[k] = plan_wgrad(j.B, j.Cin, j.Cout, j.T, j.K);
+                plan[k] = plan_wgrad(j.B, j.Cin, j.Cout, j.T, j.K, per_cu);
                 pairs[k] = ((long long)j.B * ((j.T + 31) / 32) + 1) / 2;
                 units += pairs[k] * plan[k].regions;
                 if (pairs[k] > longest) longest = pairs[k];
@@ -1920,7 +2006,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 }
                 const int pieces = product_pieces();
                 if (v == 3)
-                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, true, true>), dim3(first), dim3(512), 2 * lds1, st, pk);
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, true, true>), dim3(first), dim3(512), WGRAD_BFN_LDS, st, pk);
                 else if (pieces == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else if (pieces == 1)

@@ -73,7 +73,7 @@ def test_conv_layers_on_bfloat16_tensors(dev, bf16_storage, shape):
     xp = F.pad(x.double(), (1, 1))
     ref = s * torch.stack([torch.einsum("bot,bit->oi", _r(gm.float()), xp[:, :, j:j + T]) for j in range(3)], dim=2)
     assert gw.dtype == torch.float32 and rel(gw, ref) < 2e-3, rel(gw, ref)  # (the masked gradient is rounded to bf16 as an operand)
-    assert rel(gb, gm.sum(dim=(0, 2))) < 1e-4
+    assert rel(gb, _r(gm.float()).sum(dim=(0, 2))) < 1e-4  # (the bias gradient sums the same rounded operand)
 
 
 def test_fused_generator_layer_on_bfloat16(dev, bf16_storage):
@@ -242,8 +242,8 @@ def test_layer_at_512_samples(dev, bf16_storage):
     assert rel(gx[pick.to(dev)], F.conv_transpose1d(gys * m, wq, padding=1)) < ROUND
     # weight gradient: every sample contributes; the masked gradient is an operand rounded to bfloat16
     gm = (gy.float() * torch.where(y.float() > 0, 1.0, 0.2) * r[:, :, None])
-    gb_ref = gm.double().sum(dim=(0, 2))
     gm = gm.bfloat16().double()
+    gb_ref = gm.sum(dim=(0, 2))  # (the bias gradient sums the same rounded operand)
     xp = F.pad(x.double(), (1, 1))
     ref = s * torch.stack([torch.einsum("bot,bit->oi", gm, xp[:, :, j:j + T]) for j in range(3)], dim=2)
     assert rel(gw, ref) < 1e-5, rel(gw, ref)
