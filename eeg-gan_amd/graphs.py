@@ -10,6 +10,8 @@ hipGraph and replayed with fresh inputs copied into static buffers.
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import inspect
 import os
 from typing import Callable, Optional
@@ -19,6 +21,24 @@ import torch
 from . import layers, ops
 from .trainer import Trainer
 from .utils import cudize
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """``torch.cuda.graph(graph)`` with the garbage collector out of the way.  A collection that starts while a stream
+    is capturing (on any thread: autograd's backward thread allocates Python objects too) can free device objects of
+    earlier, unrelated work -- the graphs, streams and tensors of a discarded trainer that sat in a reference cycle --
+    and the runtime calls that release them are not allowed while a capture in the default (global) mode is under
+    way: the process aborts.  So: collect first, outside the capture, and keep the collector off until it ends."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class GraphedCall:
@@ -36,7 +56,7 @@ class GraphedCall:
         torch.cuda.synchronize()
         ops.bump_weights_epoch()  # every derived weight view is rebuilt inside the captured region
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture(self.graph):
             self.out = fn()
 
     def __call__(self):
@@ -146,7 +166,7 @@ class _SplitCriticIteration:
             self.graphs = [torch.cuda.CUDAGraph() for _ in self.parts]
             results = []
             for graph, part in zip(self.graphs, self.parts):
-                with torch.cuda.graph(graph):
+                with capture(graph):
                     results.append(chain(part))
             # Data-parallel: the closing work is two graphs with a collective started behind each, so that the
             # first bucket (the full-length layer's weights: most of the bytes) is summed over the ranks while
@@ -155,12 +175,12 @@ class _SplitCriticIteration:
             self.graph_early = torch.cuda.CUDAGraph() if bucketed else None
             self.graph_late = torch.cuda.CUDAGraph()
             if bucketed:
-                with torch.cuda.graph(self.graph_early):
+                with capture(self.graph_early):
                     early = close_early(results)
-                with torch.cuda.graph(self.graph_late):
+                with capture(self.graph_late):
                     self.out = close_late(results, early)
             else:
-                with torch.cuda.graph(self.graph_late):
+                with capture(self.graph_late):
                     self.out = close_late(results, close_early(results))
         except BaseException:
             ops.discard_direct_grads()

@@ -649,6 +649,26 @@ def _autograd_trainer():
     return AutogradTrainer
 
 
+def test_no_garbage_collection_during_capture(dev):
+    """A collection that starts while a stream is capturing can release device objects of earlier work (graphs and
+    tensors of a discarded trainer in a reference cycle), which the runtime forbids during a capture and answers by
+    aborting the process: captures run with the collector switched off, after one collection outside them."""
+    import gc
+    from eeggan_amd.graphs import GraphedCall
+    seen = []
+    x = torch.ones(1024, device=dev)
+
+    def fn():
+        seen.append(gc.isenabled())
+        return x * 2.0
+
+    assert gc.isenabled()
+    call = GraphedCall(fn)
+    assert seen[:-1] == [True] * (len(seen) - 1) and seen[-1] is False  # warm-up runs, then the captured run
+    assert gc.isenabled()
+    assert float(call()[0]) == 2.0
+
+
 def test_graph_replay_equals_eager(dev):
     """Two training steps follow the same trajectory (a) with weight gradients accumulated by autograd
     on one stream, (b) with the trainer's default side-stream accumulation into persistent buffers,
