@@ -26,6 +26,7 @@ namespace eeggan {
 namespace {
 
 constexpr int SUB = 40;  // LDS floats per 32-sample subtile (see header comment)
+constexpr int WGRAD_W4_PER_CU = 2;  // workgroups per CU of the weight gradient's four-wave form (43 KB of LDS each)
 constexpr int WGRAD_LDH = 88;  // halfwords per LDS row of the weight gradient's bfloat16-native tiles (see wgrad_body)
 // LDS of that form: two buffers of two tiles, or the eight waves' closing exchange of sums, whichever is larger
 constexpr size_t WGRAD_BFN_LDS = (size_t)4 * (3 * 16 + 1) * 64 * sizeof(float) > (size_t)2 * 2 * 64 * WGRAD_LDH * 2
@@ -1068,8 +1069,12 @@ unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next w
 // pieces with the six leading piece products kept (fp32-exact to 2^-24; see conv_ws.hip): 18 MFMAs of 16
 // time steps replace 24 fp32 MFMAs of 2.
 // XBF / GBF: x / gy (and mask_y) are bfloat16 in memory.
-template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
+// W4 (split fp32 form): four waves per workgroup, each taking BOTH subtiles of a pair, and ONE LDS buffer (43 KB), so
+// that two workgroups share a CU.  Per SIMD that is still two waves, but of two workgroups that do not wait at each
+// other's barriers: while one waits for its loads, the other multiplies.
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
+    static_assert(!W4 || (SPLIT == 3 && !XBF && !GBF), "four-wave form: the split fp32 products");
     static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
     static_assert(!(FULL && (XBF || GBF)) || (SPLIT == 1 && XBF && GBF), "bf16 storage, predicate-free form: bf16 products, both sides");
     typedef typename ActT<XBF>::T XT;
@@ -1099,9 +1104,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     // SPLIT runs eight waves, two per SIMD: wave w and wave w + 4 share an output tile and take one subtile of every
     // pair each (their sums meet through LDS at the end).  On the bf16 pipe the matrix work of an iteration is
     // shorter than the splitting that feeds it, and a wave alone on its SIMD runs the two one after the other.
-    constexpr int NTHR = SPLIT ? 512 : 256;
+    constexpr int NTHR = (SPLIT && !W4) ? 512 : 256;
     const int wave = tid >> 6;
-    const int part = SPLIT ? wave >> 2 : 0;
+    const int part = (SPLIT && !W4) ? wave >> 2 : 0;
     const int cot = (wave >> 1) & 1, cit = wave & 1;
     const int co0 = (region / a.nci) * 64;
     const int ci0 = (region % a.nci) * 64;
@@ -1155,8 +1160,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             return;
         }
         if constexpr (SPLIT) {
-            const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h + part * SUB;  // (this wave's subtile of the pair)
-            const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h + part * SUB;
+          // (four-wave form: both subtiles of the pair, one after the other)
+#pragma unroll
+          for (int sub = W4 ? 0 : part; sub < (W4 ? 2 : part + 1); ++sub) {
+            const float* Gr = Gs + (cot * 32 + l31) * LD + 4 + 8 * h + sub * SUB;  // (this wave's subtile of the pair)
+            const float* Xr = Xs + (cit * 32 + l31) * LD + 4 + 8 * h + sub * SUB;
             // Two halves of 16 time steps; per half this lane's 8 time steps of the gradient row and the 10 input
             // samples around them.  All LDS reads first; the operands of the second half are prepared (VALU) in the
             // MFMA gaps of the first half -- a vector instruction between two MFMAs of the same wave is free, a block
@@ -1251,7 +1259,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             }
             __builtin_amdgcn_sched_barrier(0);
             multiply(ob);
-            return;
+          }
+          return;
         }
         const float* Gp = Gs + (cot * 32 + l31) * LD + 4 + 4 * h;
         const float* Xp = Xs + (cit * 32 + l31) * LD + 4 + 4 * h;
@@ -1386,8 +1395,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         EEGGAN_STAMP(0, 7);
         for (int it = it0; it < it1; ++it) {
             const bool more = it + 1 < it1;
-            float* cur = smem + ((it - it0) & 1) * BUFF;
-            float* nxt = smem + ((it - it0 + 1) & 1) * BUFF;
+            float* cur = smem + (W4 ? 0 : ((it - it0) & 1) * BUFF);
+            float* nxt = smem + (W4 ? 0 : ((it - it0 + 1) & 1) * BUFF);
             EEGGAN_STAMP(it - it0, 0);
             if (more) issue(it + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1395,6 +1404,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             mfma_block(cur, cur + TILEF);
             EEGGAN_STAMP(it - it0, 2);
             __builtin_amdgcn_sched_barrier(0);
+            if (W4) __syncthreads();  // (one buffer: every wave has read its operands before the tiles are replaced)
             if (more) commit(nxt, nxt + TILEF);
             EEGGAN_STAMP(it - it0, 3);
             __syncthreads();
@@ -1423,7 +1433,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
         }
     }
 
-    if (SPLIT) {
+    if (SPLIT && !W4) {
         // waves 4..7 hand their sums to waves 0..3 (the staging buffers are free: every path above ends in a barrier
         // or never used them)
         float* red = smem + ((wave & 3) * (K * 16 + 1)) * 64 + lane;
@@ -1477,15 +1487,16 @@ struct WgradPack {
 };
 
 // (the bfloat16-native form asks for registers that let two workgroups of eight waves share a CU: four waves per SIMD)
-template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
-__global__ __launch_bounds__(SPLIT ? 512 : 256, (FULL && SPLIT == 1 && XBF && GBF) ? 4 : 1) void conv_wgrad_multi_kernel(WgradPack pk) {
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false>
+__global__ __launch_bounds__((SPLIT && !W4) ? 512 : 256, (FULL && SPLIT == 1 && XBF && GBF) ? 4 : (W4 ? WGRAD_W4_PER_CU : 1))
+void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
     int k = 0;
     while (k + 1 < pk.n && blk >= pk.first[k + 1]) ++k;
     const WgradArgs a = pk.j[k];
     const int local = blk - pk.first[k];
     const int region = local / a.nsplit;
-    wgrad_body<K, FULL, SPLIT, XBF, GBF>(a, local - region * a.nsplit, region);
+    wgrad_body<K, FULL, SPLIT, XBF, GBF, W4>(a, local - region * a.nsplit, region);
 }
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
@@ -1533,8 +1544,17 @@ struct WgradPlan {
     size_t slab_elems, bytes;
 };
 
-// ``per_cu``: workgroups the kernel variant places on one CU (2 for the bfloat16-native form).  The workspace is
-// always sized for 2, so that one size serves every variant of a layer.
+// ``per_cu``: workgroups the kernel variant places on one CU (2 for the bfloat16-native form, WGRAD_W4_PER_CU for the
+// four-wave form).  The workspace is always sized for the largest, so that one size serves every variant of a layer.
+// (comparison switch: EEGGAN_WGRAD_W4=0 keeps the eight-wave form of the split weight gradient)
+inline bool wgrad_four_wave() {
+    static const bool on = [] {
+        const char* e = getenv("EEGGAN_WGRAD_W4");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K, int per_cu = 1) {
     WgradPlan p;
     p.nco = (Cout + 63) / 64;
@@ -1551,7 +1571,7 @@ WgradPlan plan_wgrad(int B, int Cin, int Cout, int T, int K, int per_cu = 1) {
     };
     p.nsplit = splits(256 * per_cu, &p.iters);
     int unused;
-    const int most = splits(256 * 2, &unused);
+    const int most = splits(256 * WGRAD_W4_PER_CU, &unused);
     p.slab_elems = (size_t)Cout * Cin * K;
     p.bytes = ((size_t)(most > p.nsplit ? most : p.nsplit) * (p.slab_elems + Cout) * sizeof(float) + 255) & ~(size_t)255;
     return p;
@@ -1928,7 +1948,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     for (int v = 0; v < 12; ++v) {
         int idx[WG_MAXJ];
         int n = 0;
-        const int per_cu = v == 3 ? 2 : 1;  // (the bfloat16-native form: two workgroups per CU)
+        // (two workgroups per CU: the bfloat16-native form, and the four-wave form of the split fp32 products)
+        const bool four_wave = v == 0 && product_pieces() == 3 && wgrad_four_wave();
+        // (the generic and the 1x1 forms: four waves and one 43 KB buffer as well)
+        const int per_cu = four_wave ? WGRAD_W4_PER_CU : ((v == 3 || v / 4 >= 1) ? 2 : 1);
         const int cus = per_cu * num_cus();
         auto flush = [&]() -> int {
             if (n == 0) return 0;
@@ -2007,6 +2030,8 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 const int pieces = product_pieces();
                 if (v == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, true, true>), dim3(first), dim3(512), WGRAD_BFN_LDS, st, pk);
+                else if (four_wave)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3, false, false, true>), dim3(first), dim3(256), lds1, st, pk);
                 else if (pieces == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else if (pieces == 1)
