@@ -957,7 +957,12 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     // one-subtile tiles): batches that are not a multiple of the chip width lose up to half a round on the big tile.
     const long long cus = num_cus();
     const long long cost4 = (tiles(64, 4) + cus - 1) / cus * 4 * 20, cost1 = (tiles(64, 1) + 2 * cus - 1) / (2 * cus) * 2 * 21;
-    const bool big = tiles(64, 4) >= cus && cost4 <= cost1;
+    // (comparison switch: EEGGAN_CONV_TILE=narrow / big overrides the choice)
+    static const int forced = [] {
+        const char* e = getenv("EEGGAN_CONV_TILE");
+        return !e ? 0 : (e[0] == 'n' ? 1 : (e[0] == 'b' ? 2 : 0));
+    }();
+    const bool big = forced ? forced == 2 : (tiles(64, 4) >= cus && cost4 <= cost1);
     if constexpr (K == 3) {
         // predicate-free layers: products from bf16 pieces.  The narrow tile is 32 channels x 2 subtiles there (as many
         // tiles as 64 x 1): with the weight chunk as three piece planes that is what still fits twice on a CU.
