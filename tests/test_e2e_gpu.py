@@ -624,7 +624,12 @@ def _same_trajectory(base, other, what, moment_tol=1e-5):
             assert torch.equal(a, b), f"{what}: {k} differs with lr = 0"
         else:
             err = float((a - b).abs().max()) / max(float(a.abs().max()), 1e-30)
-            assert err < moment_tol, f"{what}: {k} differs by {err:.2e} of its scale with lr = 0"
+            # The output layer's one-element bias: its gradient is -1 (reals' mean score) + 1 (fakes') + the small
+            # drift term, i.e. ~1e-3 left over from sums of magnitude 1 -- fp32 leaves it ~1e-4 of relative accuracy,
+            # and two launch paths that sum the batch in another order (one stacked pass against two passes) differ
+            # by that much.
+            tol = max(moment_tol, 1e-4) if k.startswith("D.linear.conv.conv.bias") else moment_tol
+            assert err < tol, f"{what}: {k} differs by {err:.2e} of its scale with lr = 0"
     moved = 0
     for k, a in live_a.items():
         if k.endswith((".m", ".v", ".step")):
