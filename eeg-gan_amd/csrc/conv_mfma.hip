@@ -1079,7 +1079,7 @@ unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next w
 // other's barriers: while one waits for its loads, the other multiplies.
 template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
-    static_assert(!W4 || (SPLIT == 3 && !XBF && !GBF), "four-wave form: the split fp32 products");
+    static_assert(!W4 || (SPLIT != 0 && !XBF && !GBF), "four-wave form: products on the bf16 pipe, float32 tensors");
     static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
     static_assert(!(FULL && (XBF || GBF)) || (SPLIT == 1 && XBF && GBF), "bf16 storage, predicate-free form: bf16 products, both sides");
     typedef typename ActT<XBF>::T XT;
@@ -1954,7 +1954,7 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
         int idx[WG_MAXJ];
         int n = 0;
         // (two workgroups per CU: the bfloat16-native form, and the four-wave form of the split fp32 products)
-        const bool four_wave = v == 0 && product_pieces() == 3 && wgrad_four_wave();
+        const bool four_wave = v == 0 && product_pieces() != 0 && wgrad_four_wave();
         // (the generic and the 1x1 forms: four waves and one 43 KB buffer as well)
         const int per_cu = four_wave ? WGRAD_W4_PER_CU : ((v == 3 || v / 4 >= 1) ? 2 : 1);
         const int cus = per_cu * num_cus();
@@ -2035,8 +2035,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 const int pieces = product_pieces();
                 if (v == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, true, true>), dim3(first), dim3(512), WGRAD_BFN_LDS, st, pk);
-                else if (four_wave)
+                else if (four_wave && pieces == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3, false, false, true>), dim3(first), dim3(256), lds1, st, pk);
+                else if (four_wave)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, false, false, true>), dim3(first), dim3(256), lds1, st, pk);
                 else if (pieces == 3)
                     hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3>), dim3(first), dim3(512), 2 * lds1, st, pk);
                 else if (pieces == 1)
