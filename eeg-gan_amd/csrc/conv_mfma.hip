@@ -1475,6 +1475,154 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
     }
 }
 
+// Weight gradient of a 1x1 layer with a thin side (at most 8 channels: from_rgb, to_rgb) at large batches, on the
+// vector ALUs.  The matrix-core kernel pads the thin side to 64 channels and runs its generic staging; here the work
+// is what it is -- one pass over the wide tensor, a handful of multiply-adds per element -- and the kernel streams:
+// a workgroup owns a run of tiles (one sample, 128 time steps, 64 wide channels), stages the wide tile (with the
+// fused backward mask) and the thin tile in LDS with full-line loads, the next tile's loads in flight meanwhile, and
+// thread (channel c, quarter q) keeps the W sums of its wide row over its 32 time steps of every tile in registers.
+//   THIN_X: x is the thin tensor (from_rgb: gw[co][w] = sum gy[co] x[w]); else gy is (to_rgb: gw[w][ci] = sum gy[w] x[ci]).
+// Partial sums per split land in the job's slabs like the matrix-core kernels' (same reduction afterwards).
+constexpr int WT_TILE = 128;              // time steps per tile
+constexpr int WT_LD = WT_TILE + 4;        // LDS row stride of the wide tile in floats ((WT_LD / 4) odd)
+template <bool THIN_X, bool XBF, bool GBF>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradArgs a) {
+    typedef typename ActT<XBF>::T XT;
+    typedef typename ActT<GBF>::T GT;
+    typedef typename std::conditional<THIN_X, GT, XT>::type WT;  // storage type of the wide tensor
+    typedef typename std::conditional<THIN_X, XT, GT>::type NT_;  // ... of the thin one
+    constexpr bool WBF = THIN_X ? GBF : XBF;
+    constexpr int EPV = WBF ? 8 : 4;                    // elements per 16-byte vector of the wide tensor
+    constexpr int WVEC = 64 * WT_TILE / EPV / 256;      // 16-byte vectors of the wide tile per thread (4 | 8)
+    constexpr int VROW = WT_TILE / EPV;                 // vectors per wide row
+    __shared__ __attribute__((aligned(16))) float wide_s[64 * WT_LD];
+    __shared__ __attribute__((aligned(16))) float thin_s[8 * WT_TILE];
+    const int tid = threadIdx.x;
+    const int Cw = THIN_X ? a.Cout : a.Cin, Cn = THIN_X ? a.Cin : a.Cout;  // wide / thin channel counts
+    const WT* const W0 = reinterpret_cast<const WT*>(THIN_X ? a.gy : a.x);
+    const NT_* const N0 = reinterpret_cast<const NT_*>(THIN_X ? a.x : a.gy);
+    const GT* const M0 = reinterpret_cast<const GT*>(a.mask_y);
+    const bool masked = THIN_X && a.mask_y != nullptr;  // (the mask belongs to gy; a thin gy carries none here)
+    const int c0 = blockIdx.y * 64;
+    const int tiles_per_sample = a.T / WT_TILE;
+    const int ntiles = a.B * tiles_per_sample;
+    const int split = blockIdx.x;
+    const int t_begin = split * a.iters, t_end = min(t_begin + a.iters, ntiles);
+
+    typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+    u32x4w wv[WVEC], mv[WVEC];
+    float md[WVEC];
+    float nv[4];  // the thin tile: 8 rows x 128 steps = 1024 values, four per thread
+    auto issue = [&](int tile) {
+        const int b = tile / tiles_per_sample, t0 = (tile - b * tiles_per_sample) * WT_TILE;
+#pragma unroll
+        for (int i = 0; i < WVEC; ++i) {
+            const int v = tid + 256 * i, row = v / VROW, q = v - row * VROW;
+            const bool ok = c0 + row < Cw;
+            const long long off = ((long long)b * Cw + (ok ? c0 + row : 0)) * a.T + t0 + q * EPV;
+            wv[i] = *reinterpret_cast<const u32x4w*>(W0 + off);
+            if (masked) {
+                mv[i] = *reinterpret_cast<const u32x4w*>(M0 + off);
+                md[i] = a.mask_drop ? a.mask_drop[b * Cw + (ok ? c0 + row : 0)] : 1.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, row = e / WT_TILE, t = e - row * WT_TILE;
+            nv[i] = row < Cn ? ld1(N0 + ((long long)b * Cn + row) * a.T + t0 + t) : 0.f;
+        }
+    };
+    // one 16-byte vector of the wide tensor as EPV floats (bfloat16: widened)
+    auto widen_vec = [](const u32x4w& u, float (&out)[EPV]) {
+        if constexpr (WBF) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                out[2 * k] = __builtin_bit_cast(float, u[k] << 16);
+                out[2 * k + 1] = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+            }
+        } else {
+            const f32x4 f = __builtin_bit_cast(f32x4, u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = f[k];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < WVEC; ++i) {
+            const int v = tid + 256 * i, row = v / VROW, q = v - row * VROW;
+            const bool ok = c0 + row < Cw;
+            float vals[EPV], ms[EPV];
+            widen_vec(wv[i], vals);
+            if (masked) widen_vec(mv[i], ms);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float g = vals[e];
+                if (masked) g *= ms[e] > 0.f ? md[i] : md[i] * a.mask_slope;
+                vals[e] = ok ? g : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < EPV / 4; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = vals[4 * k + e];
+                *reinterpret_cast<f32x4*>(wide_s + row * WT_LD + q * EPV + 4 * k) = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) thin_s[tid + 256 * i] = nv[i];
+    };
+
+    const int c = tid & 63, qt = tid >> 6;  // wide row and quarter of the tile's time steps
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    if (t_begin < t_end) issue(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();  // the previous tile has been read
+        commit();
+        __syncthreads();
+        if (tile + 1 < t_end) issue(tile + 1);
+        const float* wr = wide_s + c * WT_LD + 32 * qt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(wr + 4 * k);
+            if (THIN_X) bsum += (g[0] + g[1]) + (g[2] + g[3]);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                if (w < Cn) {  // (uniform)
+                    const f32x4 n = *reinterpret_cast<const f32x4*>(thin_s + w * WT_TILE + 32 * qt + 4 * k);
+                    acc[w] += (g[0] * n[0] + g[1] * n[1]) + (g[2] * n[2] + g[3] * n[3]);
+                }
+            }
+        }
+        if (!THIN_X && c < Cn) {  // bias gradient of a thin gy: row c of the thin tile, this quarter
+            const float* nr = thin_s + c * WT_TILE + 32 * qt;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) bsum += nr[k];
+        }
+    }
+    // the four quarters' sums meet in LDS (in a fixed order), then one thread per wide row writes the slab
+    __syncthreads();
+    float* red = wide_s;  // [4][64][9]
+#pragma unroll
+    for (int w = 0; w < 8; ++w) red[(qt * 64 + c) * 9 + w] = acc[w];
+    red[(qt * 64 + c) * 9 + 8] = bsum;
+    __syncthreads();
+    if (qt != 0) return;
+    float tot[9];
+#pragma unroll
+    for (int w = 0; w < 9; ++w) tot[w] = (red[c * 9 + w] + red[(64 + c) * 9 + w]) + (red[(128 + c) * 9 + w] + red[(192 + c) * 9 + w]);
+    const long long E = (long long)a.Cout * a.Cin;
+    float* slab = a.ws + (long long)split * E;
+    if (c0 + c < Cw) {
+        for (int w = 0; w < Cn; ++w) {
+            if (THIN_X) slab[(long long)(c0 + c) * a.Cin + w] = tot[w];   // [co = wide][ci = thin]
+            else slab[(long long)w * a.Cin + c0 + c] = tot[w];            // [co = thin][ci = wide]
+        }
+        if (THIN_X && a.ws_b) a.ws_b[(long long)split * a.Cout + c0 + c] = tot[8];
+    }
+    if (!THIN_X && a.ws_b && blockIdx.y == 0 && c < Cn) a.ws_b[(long long)split * a.Cout + c] = tot[8];
+}
+
 template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false>
 __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_wgrad_kernel(WgradArgs a) {
     wgrad_body<K, FULL, SPLIT, XBF, GBF>(a, blockIdx.x, blockIdx.y);
@@ -1551,6 +1699,15 @@ struct WgradPlan {
 
 // ``per_cu``: workgroups the kernel variant places on one CU (2 for the bfloat16-native form, WGRAD_W4_PER_CU for the
 // four-wave form).  The workspace is always sized for the largest, so that one size serves every variant of a layer.
+// (comparison switch: EEGGAN_WGRAD_THIN=0 keeps the 1x1 layers with a thin side on the matrix-core kernel)
+inline bool wgrad_thin_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("EEGGAN_WGRAD_THIN");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // (comparison switch: EEGGAN_WGRAD_W4=0 keeps the eight-wave form of the split weight gradient)
 inline bool wgrad_four_wave() {
     static const bool on = [] {
@@ -1931,7 +2088,18 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     hipStream_t st = as_stream(stream);
     constexpr size_t lds1 = (size_t)2 * 64 * (2 * SUB + 4) * sizeof(float);
     // kernel variant per job: (0 = K 3 without predicates, 1 = K 3 generic, 2 = K 1) * 4 + storage types of x and gy
-    auto variant = [](const eeggan_wgrad_job& j) {
+    // 1x1 layers with a thin side at large batches take the vector-ALU kernel, one launch per layer (below that
+    // size the shared matrix-core launch wins: its cost is the launches it saves)
+    auto thin = [](const eeggan_wgrad_job& j) {
+        const int lo = j.Cin < j.Cout ? j.Cin : j.Cout;
+        const bool thin_x = j.Cin <= j.Cout;
+        const void* wide = thin_x ? j.gy : j.x;
+        return j.K == 1 && lo <= 8 && j.T % WT_TILE == 0 && (long long)j.B * j.T >= (1ll << 18) && wgrad_thin_enabled() &&
+               (reinterpret_cast<uintptr_t>(wide) & 15) == 0 && (!j.mask_y || (reinterpret_cast<uintptr_t>(j.mask_y) & 15) == 0) &&
+               !(j.mask_y && !thin_x);
+    };
+    auto variant = [&](const eeggan_wgrad_job& j) {
+        if (thin(j)) return -1;
         const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
         return (j.K == 3 ? (full ? 0 : 1) : 2) * 4 + (j.x_bf16 ? 2 : 0) + (j.gy_bf16 ? 1 : 0);
     };
@@ -1944,11 +2112,55 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                        "conv1d_wgrad_partial_multi: job %d: workspace too small (%zu < %zu bytes)", i,
                        j.workspace_bytes, p.bytes);
         const int v = variant(j);
+        if (v < 0) continue;
         // bfloat16 activations: the predicate-free k = 3 layers with both tensors bfloat16 and bf16 products, and
         // the 1x1 layers in any combination
         EEGGAN_REQUIRE((v & 3) == 0 || v / 4 == 2 || (v == 3 && product_pieces() == 1),
                        "conv1d_wgrad_partial_multi: job %d: bfloat16 activations need K = 1, or K = 3 with Cin %% 64 == 0, "
                        "Cout %% 64 == 0, T %% 32 == 0, both tensors bfloat16 and the bf16 matrix precision", i);
+    }
+    for (int i = 0; i < njobs; ++i) {
+        const eeggan_wgrad_job& j = jobs[i];
+        if (!thin(j)) continue;
+        const bool thin_x = j.Cin <= j.Cout;
+        const int Cw = thin_x ? j.Cout : j.Cin;
+        const int groups = (Cw + 63) / 64;
+        const long long tiles = (long long)j.B * (j.T / WT_TILE);
+        const size_t E = (size_t)j.Cout * j.Cin;
+        long long nsplit = 4ll * num_cus() / groups;  // (38 KB of LDS and four waves per workgroup: four per CU)
+        const long long room = (long long)(j.workspace_bytes / ((E + j.Cout) * sizeof(float)));
+        if (nsplit > room) nsplit = room;
+        if (nsplit > tiles) nsplit = tiles;
+        EEGGAN_REQUIRE(nsplit >= 1, "conv1d_wgrad_partial_multi: job %d: workspace too small", i);
+        const long long iters = (tiles + nsplit - 1) / nsplit;
+        nsplit = (tiles + iters - 1) / iters;
+        WgradArgs a{};
+        a.x = j.x; a.gy = j.gy; a.mask_y = j.mask_y; a.mask_drop = j.mask_y ? j.mask_drop : nullptr;
+        a.mask_slope = j.mask_slope;
+        a.ws = static_cast<float*>(j.workspace);
+        a.ws_b = j.want_bias ? a.ws + (size_t)nsplit * E : nullptr;
+        a.B = j.B; a.Cin = j.Cin; a.Cout = j.Cout; a.T = j.T;
+        a.nsplit = (int)nsplit; a.iters = (int)iters;
+        a.x_bf16 = j.x_bf16; a.gy_bf16 = j.gy_bf16;
+        const dim3 grid((unsigned)nsplit, (unsigned)groups);
+        const int tv = (thin_x ? 4 : 0) + (j.x_bf16 ? 2 : 0) + (j.gy_bf16 ? 1 : 0);
+        switch (tv) {
+            case 0: hipLaunchKernelGGL((wgrad_thin_kernel<false, false, false>), grid, dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((wgrad_thin_kernel<false, false, true>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((wgrad_thin_kernel<false, true, false>), grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((wgrad_thin_kernel<false, true, true>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((wgrad_thin_kernel<true, false, false>), grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((wgrad_thin_kernel<true, false, true>), grid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((wgrad_thin_kernel<true, true, false>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((wgrad_thin_kernel<true, true, true>), grid, dim3(256), 0, st, a); break;
+        }
+        if (check_launch("conv1d_wgrad_partial_multi (thin 1x1 layer)")) return 1;
+        eeggan_reduce_job& rw = jobs_w[i];
+        rw.slabs = a.ws; rw.out = nullptr; rw.elems = (int64_t)E; rw.nsplit = (int)nsplit;
+        rw.scale = j.in_scale; rw.beta = 0.f; rw.reserved = 0;
+        eeggan_reduce_job& rb = jobs_b[i];
+        rb.slabs = a.ws_b; rb.out = nullptr; rb.elems = j.want_bias ? j.Cout : 0; rb.nsplit = (int)nsplit;
+        rb.scale = 1.f; rb.beta = 0.f; rb.reserved = 0;
     }
     for (int v = 0; v < 12; ++v) {
         int idx[WG_MAXJ];

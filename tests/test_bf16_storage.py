@@ -283,3 +283,25 @@ def test_critic_iteration_at_512_samples_against_float32(dev, bf16_storage):
     worst = max((rel(g16[k], g32[k]), k) for k in g32 if float(g32[k].abs().max()) > 0)
     print(f"512 samples, bf16 storage against float32: loss {l16:.5f} / {l32:.5f}, worst gradient {worst[0]:.2e} ({worst[1]})")
     assert worst[0] < GRAD_BOUND, worst
+
+
+@pytest.mark.parametrize("xb,yb", [(False, True), (True, False), (True, True)])
+def test_thin_wgrad_large_batch_between_storage_types(dev, bf16_storage, xb, yb):
+    """The thin 1x1 layers' weight gradient at a large batch (its own vector kernel) with bfloat16 on either side."""
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(17)
+    B, T = 140, 1920
+    cast = lambda t, bf: t.bfloat16() if bf else t
+    for Cin, Cout, masked in ((5, 64, True), (64, 5, False)):
+        x = cast(torch.randn(B, Cin, T, generator=gen), xb)
+        gy = cast(torch.randn(B, Cout, T, generator=gen), yb)
+        job = dict(x=x.to(dev), gy=gy.to(dev), K=1, in_scale=0.3)
+        geff = gy.double()
+        if masked:
+            y = cast(torch.randn(B, Cout, T, generator=gen), yb)
+            drop = torch.rand(B, Cout, generator=gen) + 0.5
+            job.update(mask_y=y.to(dev), mask_drop=drop.to(dev), mask_slope=0.2)
+            geff = geff * torch.where(y.double() > 0, 1.0, 0.2) * drop.double()[:, :, None]
+        (gw, gb), = ops.conv1d_wgrad_group_raw([job])
+        ref = 0.3 * torch.einsum("bot,bit->oi", geff.to(dev), x.double().to(dev))[:, :, None]
+        assert rel(gw, ref) < 1e-5 and rel(gb, geff.sum(dim=(0, 2))) < 1e-5, (Cin, Cout, rel(gw, ref))

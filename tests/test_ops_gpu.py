@@ -247,6 +247,31 @@ def test_direct_wgrad_solo_submission(dev):
     assert rel(wd.grad, gw_ref) < TOL and rel(bd.grad, gb_ref) < TOL
 
 
+@pytest.mark.parametrize("shape", [(140, 5, 64, 1920, True), (140, 64, 5, 1920, False), (70, 5, 256, 3840, True),
+                                   (280, 128, 5, 1024, False), (140, 7, 100, 1920, True)])
+def test_thin_wgrad_large_batch(dev, shape):
+    """1x1 layers with a thin side (from_rgb, to_rgb) at batch sizes where their weight gradient takes the vector
+    kernel of its own (B * T >= 2^18): against fp64, with the fused backward mask where the layer has one, and against
+    the matrix-core route on the same inputs."""
+    import os
+    ops = _ops()
+    B, Cin, Cout, T, masked = shape
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(B, Cin, T, generator=g)
+    gy = torch.randn(B, Cout, T, generator=g)
+    job = {"x": x.to(dev), "gy": gy.to(dev), "K": 1, "in_scale": 0.37, "need_bias": True}
+    geff = gy.double()
+    if masked:
+        y = torch.randn(B, Cout, T, generator=g)
+        drop = torch.rand(B, Cout, generator=g) + 0.5
+        job.update(mask_y=y.to(dev), mask_drop=drop.to(dev), mask_slope=0.2)
+        geff = geff * torch.where(y > 0, 1.0, 0.2).double() * drop.double()[:, :, None]
+    ref_w = 0.37 * torch.einsum("bot,bit->oi", geff.to(dev), x.double().to(dev))[:, :, None]
+    ref_b = geff.sum(dim=(0, 2))
+    (gw, gb), = ops.conv1d_wgrad_group_raw([job])
+    assert rel(gw, ref_w) < TOL and rel(gb, ref_b) < TOL, (rel(gw, ref_w), rel(gb, ref_b))
+
+
 def test_conv_rejects_bad_arguments(dev):
     ops = _ops()
     from eeggan_amd._lib import EegganError
