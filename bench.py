@@ -226,6 +226,17 @@ def conv_ws_family_flops(trainer_factory):
     return total
 
 
+def device_info(dev):
+    """What the run was measured on (boxes of one pool differ by several per cent at equal CU counts)."""
+    p = torch.cuda.get_device_properties(dev)
+    info = {"name": p.name, "cus": p.multi_processor_count}
+    for key, attr in (("clock_mhz", "clock_rate"), ("memory_clock_mhz", "memory_clock_rate")):
+        v = getattr(p, attr, None)
+        if v:
+            info[key] = round(v / 1000)
+    return info
+
+
 def in_step_figures(flops, launches):
     """The weight-stationary family inside the training step: flops counted live, kernel time per step from
     the committed rocprofv3 summary of this command (profiles/r02_bench_per_kernel.txt), if it is there."""
@@ -377,7 +388,7 @@ def main():
             "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha={args.alpha:g}, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
                        "parallelism": f"dp{world}", "drop_noise": args.drop_mode, "activation_storage": args.storage,
-                       "launch": type(tr).__name__},
+                       "launch": type(tr).__name__, "device": device_info(dev)},
         }
         out["roofline"] = conv_roofline(dev, args.batch, T)
         # (the committed per-kernel profile belongs to the headline configuration only)
