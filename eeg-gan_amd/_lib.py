@@ -60,6 +60,7 @@ SIGNATURES = {
     "eeggan_channel_window": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _st]),
     "eeggan_mix_batch": (_i, [_f, _f, _f, _f, _i, _sz, _st]),
     "eeggan_pow_base": (_i, [_f, _f, _sz, _fl, _st]),
+    "eeggan_lognormal_fill": (_i, [_f, _sz, _fl, C.c_ulonglong, C.c_uint, C.c_void_p, _st]),
     "eeggan_resample": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "eeggan_resample_quads": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "eeggan_mbstd_workspace": (_sz, [_i, _i, _i, _i]),

@@ -325,6 +325,63 @@ __global__ __launch_bounds__(256) void pow_base_kernel(const float* __restrict__
         out[i] = expf(x[i] * log_base);
 }
 
+// GDrop multipliers drawn on the device in one launch: out[i] = base ** z_i, z_i ~ N(0, 1) (layers.py:36, on the
+// device instead of np.random).  Philox-4x32-10 (Salmon et al., SC'11) keyed by (seed, salt), counter (i / 4, epoch);
+// four uniforms give four normals by Box-Muller.  ``state`` is three words of device memory owned by the caller:
+// the 64-bit epoch, read by every thread at its start, and a count of finished workgroups -- the LAST workgroup to
+// finish advances the epoch and leaves the count at zero, so every launch, and every replay of a captured launch,
+// draws a fresh stream with no host involvement and no second kernel.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ __launch_bounds__(256) void lognormal_fill_kernel(float* __restrict__ out, size_t n, float log2_base,
+                                                             unsigned key0, unsigned key1, unsigned* state) {
+    // (device-scope loads: the epoch comes from where the previous launch's last workgroup stored it)
+    const unsigned e0 = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned e1 = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; 4 * i4 < n; i4 += (size_t)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)i4, (unsigned)(i4 >> 32), e0, e1};
+        unsigned k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // u1 in (0, 1], u2 in [0, 1): 24 random bits each.  The hardware's sine and cosine take their
+            // argument in revolutions, and its base-2 logarithm is accurate to an ulp: no range reduction needed.
+            const float u1 = ((float)(c[2 * h] >> 8) + 1.f) * (1.f / 16777216.f);
+            const float u2 = (float)(c[2 * h + 1] >> 8) * (1.f / 16777216.f);
+            const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1
+            z[2 * h] = r * __builtin_amdgcn_cosf(u2);
+            z[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * i4 + e < n) out[4 * i4 + e] = exp2f(z[e] * log2_base);
+    }
+    // The last workgroup to get here advances the epoch.  No fence: a thread's epoch has arrived before it computes
+    // with it, hence before the barrier; the count is a relaxed device-scope atomic; and the kernel's end publishes
+    // the last workgroup's plain stores to the next launch.  (A device-scope fence here makes every workgroup write
+    // the L2 of its XCD back, including lines of kernels that run beside this one.)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(&state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            const unsigned lo = e0 + 1u;
+            state[0] = lo;
+            state[1] = e1 + (lo == 0u ? 1u : 0u);
+            __hip_atomic_store(&state[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -631,6 +688,16 @@ extern "C" int eeggan_mix_batch(const float* real, const float* fake, const floa
     hipLaunchKernelGGL(mix_batch_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), real, fake, mix, out, n,
                        per);
     return check_launch("mix_batch");
+}
+
+extern "C" int eeggan_lognormal_fill(float* out, size_t count, float base, unsigned long long seed, unsigned int salt,
+                                     unsigned int* state, void* stream) {
+    EEGGAN_REQUIRE(out && state && count > 0 && base > 0.f, "lognormal_fill: bad argument");
+    long long blocks = ((long long)((count + 3) / 4) + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(lognormal_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, count, log2f(base),
+                       (unsigned)seed ^ (salt * 0x9E3779B9u), (unsigned)(seed >> 32) ^ 0x85EBCA6Bu, state);
+    return check_launch("lognormal_fill");
 }
 
 extern "C" int eeggan_pow_base(const float* x, float* out, size_t count, float base, void* stream) {

@@ -60,18 +60,58 @@ class batch_segments:
 
 
 class _DropPool:
-    """Device-mode multipliers are drawn CHUNK values at a time (one normal draw + one power kernel)
-    and handed out as slices, instead of two tiny launches per layer and pass.  A chunk is never
+    """Device-mode multipliers are drawn CHUNK values at a time (one launch of the library's counter-based
+    generator) and handed out as slices, instead of two tiny launches per layer and pass.  A chunk is never
     written again after it is filled, so slices saved for backward stay valid; ``reset`` drops the
-    current chunk so that an iteration (and a captured graph of it) starts with a fresh draw."""
+    current chunk so that an iteration (and a captured graph of it) starts with a fresh draw.
+
+    The generator's state (an epoch the kernel itself advances) lives in device memory, one row of a zeroed table
+    per user.  Eager draws share a row per (device, stream): launches on one stream run one after the other.  Every
+    draw recorded during a graph capture gets a row of its own: the graphs of one iteration are captured on one
+    stream but replayed side by side on several, and a replay draws a new stream of values each time because its
+    row's epoch has moved on.  Tables are allocated outside captures only (memory allocated during a capture belongs
+    to the graph, and zeroing it there would be replayed too): an eager draw makes sure enough rows are left for
+    the captures that follow it, so the first draw on a device must be an eager one -- the trainers' warm-up runs."""
 
     CHUNK = 1 << 18  # one critic iteration at the final stage takes ~190 000 multipliers
+    ROWS = 4096      # per table; 16 bytes a row
+    SPARE = 256      # rows an eager draw leaves for captures
 
     def __init__(self):
         self._chunks = {}
+        self._tables = {}  # device -> [tables]: earlier ones stay alive, captured graphs hold their addresses
+        self._used = {}    # device -> rows handed out of the newest table
+        self._eager = {}   # (device, stream) -> (row tensor, salt)
+        self._salt = 0
 
     def reset(self):
         self._chunks.clear()
+
+    def _new_row(self, device):
+        dkey = str(device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        tables = self._tables.setdefault(dkey, [])
+        if not tables or self._used[dkey] + (1 if capturing else self.SPARE) > self.ROWS:
+            if capturing:
+                raise RuntimeError("device-mode GDrop: no generator state left for a draw inside a graph capture; "
+                                   "draw once outside the capture first (a warm-up run)")
+            tables.append(torch.zeros((self.ROWS, 4), device=device, dtype=torch.int32))
+            self._used[dkey] = 0
+        row = tables[-1][self._used[dkey]]
+        self._used[dkey] += 1
+        self._salt += 1
+        return row, self._salt
+
+    def _state(self, device):
+        if torch.cuda.is_current_stream_capturing():
+            return self._new_row(device)
+        key = (str(device), torch.cuda.current_stream().cuda_stream)
+        ent = self._eager.get(key)
+        if ent is None:
+            ent = self._eager[key] = self._new_row(device)
+        elif self._used[key[0]] + self.SPARE > self.ROWS:
+            self._new_row(device)  # (tops the spare rows up with a new table; the row itself goes unused)
+        return ent
 
     def take(self, n, base, device):
         # a chunk belongs to the stream that drew it: passes that run side by side on two streams draw their own
@@ -79,8 +119,9 @@ class _DropPool:
         ent = self._chunks.get(key)
         n4 = (n + 3) & ~3
         if ent is None or ent[1] + n4 > ent[0].numel():
-            normal = torch.randn(max(self.CHUNK, n4), device=device, dtype=torch.float32)
-            ent = self._chunks[key] = [ops.pow_base_raw(normal, base), 0]
+            state, salt = self._state(device)
+            buf = torch.empty(max(self.CHUNK, n4), device=device, dtype=torch.float32)
+            ent = self._chunks[key] = [ops.lognormal_fill_raw(buf, base, torch.initial_seed(), salt, state), 0]
         out = ent[0][ent[1]:ent[1] + n]
         ent[1] += n4
         return out

@@ -3,6 +3,7 @@ the same fp32 inputs) and against the per-op golden vectors produced by the refe
 
 Tolerance: 1e-4 relative in fp32 is the contract of the path; single kernels are held to 2e-5
 (norm-wise) because their fp32 rounding noise is ~1e-6."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -270,6 +271,68 @@ def test_thin_wgrad_large_batch(dev, shape):
     ref_b = geff.sum(dim=(0, 2))
     (gw, gb), = ops.conv1d_wgrad_group_raw([job])
     assert rel(gw, ref_w) < TOL and rel(gb, ref_b) < TOL, (rel(gw, ref_w), rel(gb, ref_b))
+
+
+def test_device_gdrop_multipliers(dev):
+    """The one-launch generator of the GDrop multipliers: log(out) / log(base) is standard normal (moments, a
+    Kolmogorov-Smirnov distance), successive launches on one state differ (the kernel advances it), two states give
+    unrelated streams, and the same seed reproduces the same values."""
+    from scipy import stats
+    ops = _ops()
+    n, base = 1 << 18, 1.2
+
+    def draw(state, salt, seed=1234):
+        return ops.lognormal_fill_raw(torch.empty(n, device=dev), base, seed, salt, state)
+
+    s0, s1 = torch.zeros(4, device=dev, dtype=torch.int32), torch.zeros(4, device=dev, dtype=torch.int32)
+    a, b, c = draw(s0, 0), draw(s0, 0), draw(s1, 1)
+    assert s0.cpu().tolist()[:3] == [2, 0, 0] and s1.cpu().tolist()[:3] == [1, 0, 0]
+    for t in (a, b, c):
+        z = (torch.log(t.double()) / np.log(base)).cpu().numpy()
+        assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02 and abs(stats.kurtosis(z)) < 0.05
+        assert stats.kstest(z, "norm").statistic < 0.005
+    za, zb, zc = (torch.log(t.double()) for t in (a, b, c))
+    for u, v in ((za, zb), (za, zc), (za[1:], za[:-1])):
+        assert abs(float(torch.corrcoef(torch.stack([u, v]))[0, 1])) < 0.01
+    again = draw(torch.zeros(4, device=dev, dtype=torch.int32), 0)
+    assert torch.equal(again, a)
+    odd = ops.lognormal_fill_raw(torch.empty(1001, device=dev), base, 7, 3, torch.zeros(4, device=dev, dtype=torch.int32))
+    assert torch.isfinite(odd).all() and float(odd.min()) > 0
+
+
+def test_drop_pool_in_captured_graphs(dev):
+    """The multiplier pool under graph capture: every captured draw owns a generator state, so two graphs
+    captured on one stream and replayed side by side never share one, each replay draws new values, and the
+    values stay log-normal.  (A first eager draw sets the state table up, as a trainer's warm-up run does.)"""
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import capture
+    pool = layers._DropPool()
+    n, base = 50_000, 1.2
+    first = pool.take(n, base, dev).clone()
+    outs, graphs = [], []
+    for _ in range(2):
+        g = torch.cuda.CUDAGraph()
+        with capture(g):
+            pool.reset()
+            outs.append(pool.take(n, base, dev))
+        graphs.append(g)
+    side = torch.cuda.Stream()
+    seen = [first]
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graphs[1].replay()
+        graphs[0].replay()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        seen += [o.clone() for o in outs]
+    for i, u in enumerate(seen):
+        z = torch.log(u.double()) / np.log(base)
+        assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.04
+        for v in seen[:i]:
+            assert abs(float(torch.corrcoef(torch.stack([torch.log(u.double()), torch.log(v.double())]))[0, 1])) < 0.02
+    table = pool._tables[str(dev)][0]
+    assert table[:3, 0].cpu().tolist() == [1, 3, 3] and int(table[3:].abs().sum()) == 0
 
 
 def test_conv_rejects_bad_arguments(dev):
