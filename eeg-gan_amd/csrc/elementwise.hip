@@ -326,11 +326,14 @@ __global__ __launch_bounds__(256) void pow_base_kernel(const float* __restrict__
 }
 
 // GDrop multipliers drawn on the device in one launch: out[i] = base ** z_i, z_i ~ N(0, 1) (layers.py:36, on the
-// device instead of np.random).  Philox-4x32-10 (Salmon et al., SC'11) keyed by (seed, salt), counter (i / 4, epoch);
-// four uniforms give four normals by Box-Muller.  ``state`` is three words of device memory owned by the caller:
-// the 64-bit epoch, read by every thread at its start, and a count of finished workgroups -- the LAST workgroup to
-// finish advances the epoch and leaves the count at zero, so every launch, and every replay of a captured launch,
-// draws a fresh stream with no host involvement and no second kernel.
+// device instead of np.random).  Philox-4x32-10 (Salmon et al., SC'11) keyed by (seed, salt), counter
+// (i / 4, epoch of the workgroup); four uniforms give four normals by Box-Muller.  ``state`` is LOGNORMAL_STATE_WORDS
+// words of device memory owned by the caller, zero before the first launch: one epoch per workgroup, which the
+// workgroup reads at its start and advances at its end.  So every launch, and every replay of a captured launch,
+// draws a fresh stream with no host involvement, no second kernel, and no traffic between workgroups (a count of
+// finished workgroups behind a device-scope fence made every workgroup write its XCD's L2 back; without the fence,
+// 256 atomics on one word still took longer than the generator itself).
+constexpr int LOGNORMAL_STATE_WORDS = 256;
 __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
     const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
     const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
@@ -339,11 +342,9 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsi
 }
 __global__ __launch_bounds__(256) void lognormal_fill_kernel(float* __restrict__ out, size_t n, float log2_base,
                                                              unsigned key0, unsigned key1, unsigned* state) {
-    // (device-scope loads: the epoch comes from where the previous launch's last workgroup stored it)
-    const unsigned e0 = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned e1 = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned epoch = __hip_atomic_load(&state[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; 4 * i4 < n; i4 += (size_t)gridDim.x * 256) {
-        unsigned c[4] = {(unsigned)i4, (unsigned)(i4 >> 32), e0, e1};
+        unsigned c[4] = {(unsigned)i4, (unsigned)(i4 >> 32), epoch, 0u};
         unsigned k0 = key0, k1 = key1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
@@ -366,20 +367,9 @@ __global__ __launch_bounds__(256) void lognormal_fill_kernel(float* __restrict__
         for (int e = 0; e < 4; ++e)
             if (4 * i4 + e < n) out[4 * i4 + e] = exp2f(z[e] * log2_base);
     }
-    // The last workgroup to get here advances the epoch.  No fence: a thread's epoch has arrived before it computes
-    // with it, hence before the barrier; the count is a relaxed device-scope atomic; and the kernel's end publishes
-    // the last workgroup's plain stores to the next launch.  (A device-scope fence here makes every workgroup write
-    // the L2 of its XCD back, including lines of kernels that run beside this one.)
+    // every thread has its epoch before it computes with it, hence before the barrier
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(&state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            const unsigned lo = e0 + 1u;
-            state[0] = lo;
-            state[1] = e1 + (lo == 0u ? 1u : 0u);
-            __hip_atomic_store(&state[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (threadIdx.x == 0) state[blockIdx.x] = epoch + 1u;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -694,7 +684,7 @@ extern "C" int eeggan_lognormal_fill(float* out, size_t count, float base, unsig
                                      unsigned int* state, void* stream) {
     EEGGAN_REQUIRE(out && state && count > 0 && base > 0.f, "lognormal_fill: bad argument");
     long long blocks = ((long long)((count + 3) / 4) + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > LOGNORMAL_STATE_WORDS) blocks = LOGNORMAL_STATE_WORDS;
     hipLaunchKernelGGL(lognormal_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, count, log2f(base),
                        (unsigned)seed ^ (salt * 0x9E3779B9u), (unsigned)(seed >> 32) ^ 0x85EBCA6Bu, state);
     return check_launch("lognormal_fill");

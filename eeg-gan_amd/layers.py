@@ -65,7 +65,7 @@ class _DropPool:
     written again after it is filled, so slices saved for backward stay valid; ``reset`` drops the
     current chunk so that an iteration (and a captured graph of it) starts with a fresh draw.
 
-    The generator's state (an epoch the kernel itself advances) lives in device memory, one row of a zeroed table
+    The generator's state (epochs the kernel itself advances) lives in device memory, one row of a zeroed table
     per user.  Eager draws share a row per (device, stream): launches on one stream run one after the other.  Every
     draw recorded during a graph capture gets a row of its own: the graphs of one iteration are captured on one
     stream but replayed side by side on several, and a replay draws a new stream of values each time because its
@@ -74,8 +74,8 @@ class _DropPool:
     the captures that follow it, so the first draw on a device must be an eager one -- the trainers' warm-up runs."""
 
     CHUNK = 1 << 18  # one critic iteration at the final stage takes ~190 000 multipliers
-    ROWS = 4096      # per table; 16 bytes a row
-    SPARE = 256      # rows an eager draw leaves for captures
+    ROWS = 1024      # per table; 1 KB a row
+    SPARE = 128      # rows an eager draw leaves for captures
 
     def __init__(self):
         self._chunks = {}
@@ -95,7 +95,7 @@ class _DropPool:
             if capturing:
                 raise RuntimeError("device-mode GDrop: no generator state left for a draw inside a graph capture; "
                                    "draw once outside the capture first (a warm-up run)")
-            tables.append(torch.zeros((self.ROWS, 4), device=device, dtype=torch.int32))
+            tables.append(torch.zeros((self.ROWS, ops.LOGNORMAL_STATE_WORDS), device=device, dtype=torch.int32))
             self._used[dkey] = 0
         row = tables[-1][self._used[dkey]]
         self._used[dkey] += 1

@@ -606,13 +606,17 @@ def mix_batch_raw(real, fake, mix, out=None):
     return out
 
 
+LOGNORMAL_STATE_WORDS = 256
+
+
 def lognormal_fill_raw(out, base, seed, salt, state):
-    """out[i] = base ** N(0, 1) drawn on the device in one launch; ``state``: three int32 words of device memory, zero
-    before the first call, advanced by the kernel (one state per call site that may run beside others)."""
+    """out[i] = base ** N(0, 1) drawn on the device in one launch; ``state``: LOGNORMAL_STATE_WORDS int32 words of
+    device memory, zero before the first call, advanced by the kernel (one state per call site that may run beside
+    others)."""
     if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
         raise RuntimeError("lognormal_fill: out must be a contiguous float32 device tensor")
-    if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= 3 and state.is_contiguous()):
-        raise RuntimeError("lognormal_fill: state must be three int32 words on the device")
+    if not (state.is_cuda and state.dtype == torch.int32 and state.numel() >= LOGNORMAL_STATE_WORDS and state.is_contiguous()):
+        raise RuntimeError(f"lognormal_fill: state must be {LOGNORMAL_STATE_WORDS} int32 words on the device")
     call("eeggan_lognormal_fill", out.data_ptr(), out.numel(), float(base), int(seed) & 0xFFFFFFFFFFFFFFFF, int(salt) & 0xFFFFFFFF,
          state.data_ptr(), _stream())
     return out

@@ -208,9 +208,10 @@ int eeggan_mix_batch(const float* real, const float* fake, const float* mix, flo
 /* out = base ** n elementwise (GDrop multipliers (1+strength)**N(0,1), layers.py:36). */
 int eeggan_pow_base(const float* n, float* out, size_t count, float base, void* stream);
 /* The same multipliers drawn on the device in one launch: out[i] = base ** z_i with z_i ~ N(0, 1) from a counter-based
- * generator (Philox-4x32-10, Box-Muller) keyed by (seed, salt).  state: three 32-bit words of device memory, zero before
+ * generator (Philox-4x32-10, Box-Muller) keyed by (seed, salt).  state: EEGGAN_LOGNORMAL_STATE_WORDS 32-bit words of device memory, zero before
  * the first call and owned by one call site (launches that may run side by side need states of their own): the kernel
  * advances it by itself, so a captured launch draws a new stream at every replay (GDropLayer, layers.py:26-38). */
+#define EEGGAN_LOGNORMAL_STATE_WORDS 256
 int eeggan_lognormal_fill(float* out, size_t count, float base, unsigned long long seed, unsigned int salt,
                           unsigned int* state, void* stream);
 
