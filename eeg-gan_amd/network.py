@@ -10,7 +10,8 @@ concatenation skips, network.py:157-169, 192-193, 407-418, 432-433) and
 the critic's ``input_to_all_layers``
 (network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553), and in the
 generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322)
-and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
+``to_rgb_mode`` (network.py:173-187).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -35,11 +36,25 @@ class ToRgb(nn.Sequential):
         return self[0](x, _tanh_scale=self[1].scale)
 
 
+class NormReluConv(nn.Sequential):
+    """[BatchNorm1d, ReLU, GeneralConv] (the 'biggan' to_rgb, network.py:183-185): the norm and the ReLU run as one
+    kernel pair of the library; the ``nn.BatchNorm1d`` holds the parameters and running statistics."""
+
+    def forward(self, x):
+        bn = self[0]
+        train = bn.training or bn.running_mean is None
+        if train and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        h = ops.bn_act(x, None, bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, 0.0, bn.eps,
+                       0.1 if bn.momentum is None else bn.momentum, train)
+        return self[2](h)
+
+
 class GBlock(nn.Module):
     def __init__(self, ch_in, ch_out, ch_rgb, k_size=3, initial_kernel_size=None, is_residual=False, no_tanh=False,
                  deep=False, per_channel_noise=False, to_rgb_mode="pggan", **layer_settings):
         super().__init__()
-        _require(not per_channel_noise and to_rgb_mode == "pggan", "GBlock(per_channel_noise/to_rgb_mode)")
+        _require(not per_channel_noise, "GBlock(per_channel_noise)")
         first = initial_kernel_size is not None
         hidden = max((ch_in // 4) if deep else ch_out, 4)  # (network.py:157-169: four layers through a bottleneck)
         self.convs = nn.ModuleList([
@@ -51,8 +66,24 @@ class GBlock(nn.Module):
             self.convs.append(GeneralConv(hidden, ch_out, kernel_size=k_size, **layer_settings))
         self.noises = None
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
-        to_rgb = GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings)
-        self.to_rgb = to_rgb if no_tanh else ToRgb(to_rgb, ScaledTanh())  # (network.py:188-191)
+        if to_rgb_mode == "pggan":  # (network.py:175-187)
+            to_rgb = GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings)
+        elif to_rgb_mode in ("sngan", "sagan"):
+            to_rgb = GeneralConv(ch_out, ch_rgb if to_rgb_mode == "sngan" else ch_out, kernel_size=3, act_alpha=0.2,
+                                 **rgb_settings)
+            if to_rgb_mode == "sagan":
+                to_rgb = nn.Sequential(to_rgb, GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings))
+        elif to_rgb_mode == "biggan":
+            to_rgb = NormReluConv(nn.BatchNorm1d(ch_out), nn.ReLU(),
+                                  GeneralConv(ch_out, ch_rgb, kernel_size=3, act_alpha=-1, **rgb_settings))
+        else:
+            raise ValueError()
+        if no_tanh:  # (network.py:188-191)
+            self.to_rgb = to_rgb
+        elif isinstance(to_rgb, GeneralConv) and to_rgb.act_alpha < 0:
+            self.to_rgb = ToRgb(to_rgb, ScaledTanh())
+        else:
+            self.to_rgb = nn.Sequential(to_rgb, ScaledTanh())
         self.residual = None
         if deep:
             self.residual = PassChannelResidual()
@@ -83,7 +114,7 @@ class Generator(nn.Module):
         _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not conv_only, "conditioning/conv_only")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
-        _require(to_rgb_mode == "pggan" and not per_channel_noise, "to_rgb_mode/per_channel_noise")
+        _require(not per_channel_noise, "per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
             raise ValueError("invalid rgb_generation_mode: {}".format(rgb_generation_mode))
         _require(act_norm in (None, "pixel", "batch"), f"act_norm={act_norm!r}")

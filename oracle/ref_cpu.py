@@ -63,6 +63,7 @@ class NetConfig:
     g_act_norm: Optional[str] = "pixel"    # the generator layers' norm: 'pixel' | 'batch' | None (network.py:229, 257)
     z_to_bn: bool = False                  # batch norms modulated by the latent (network.py:253, 299, 317-322)
     split_z: bool = False                  # one share of the latent per block (network.py:294-295, 317-322, 368-371)
+    to_rgb_mode: str = "pggan"             # 'sngan' | 'sagan' | 'biggan' (network.py:173-187)
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -358,10 +359,25 @@ def _skip(params, scales, path, x):
 
 
 def g_to_rgb(params, scales, prefix, h, cfg: NetConfig):
-    """to_rgb: linear 1x1 conv, then ScaledTanh unless ``no_tanh`` (network.py:175-176, 188-191)."""
-    if cfg.no_tanh:
-        return general_conv(h, params, scales, f"{prefix}.to_rgb", act_alpha=-1)
-    return torch.tanh(general_conv(h, params, scales, f"{prefix}.to_rgb.0", act_alpha=-1) * cfg.tanh_scale)
+    """to_rgb, network.py:173-191, then ScaledTanh unless ``no_tanh``.  'pggan': a linear 1x1 conv; 'sngan': a k = 3
+    conv to the signal channels with LeakyReLU(0.2); 'sagan': a k = 3 conv with LeakyReLU(0.2) that keeps the channel
+    count, then the linear 1x1 conv; 'biggan': BatchNorm1d (training mode), ReLU, a linear k = 3 conv."""
+    base = f"{prefix}.to_rgb" if cfg.no_tanh else f"{prefix}.to_rgb.0"
+    mode = cfg.to_rgb_mode
+    if mode == "pggan":
+        out = general_conv(h, params, scales, base, act_alpha=-1)
+    elif mode == "sngan":
+        out = general_conv(h, params, scales, base, act_alpha=0.2)
+    elif mode == "sagan":
+        out = general_conv(h, params, scales, f"{base}.0", act_alpha=0.2)
+        out = general_conv(out, params, scales, f"{base}.1", act_alpha=-1)
+    elif mode == "biggan":
+        out = F.relu(F.batch_norm(h, None, None, params[f"{base}.0.weight"], params[f"{base}.0.bias"], training=True,
+                                  eps=1e-5))
+        out = general_conv(out, params, scales, f"{base}.2", act_alpha=-1)
+    else:
+        raise ValueError(mode)
+    return out if cfg.no_tanh else torch.tanh(out * cfg.tanh_scale)
 
 
 def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", first: bool = False):

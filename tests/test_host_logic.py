@@ -40,7 +40,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
     with pytest.raises(NotImplementedError):
-        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "to_rgb_mode": "biggan"})
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True})
     with pytest.raises(NotImplementedError):
         Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):

@@ -2,8 +2,8 @@
 generator's 'residual' / 'mean' signal modes (332-349), the critic's input at every stage (533-549), plain layers
 (ReLU, no equalization, xavier init, to_rgb without tanh, latents not normalised, no MinibatchStddev), separable
 layers, deep blocks, self attention (layers.py:41-64), batch norm in the generator plain and modulated by the latent
-(layers.py:93-134) and the generator loss's random multiplier and feature-matching
-term (losses.py:46, 62-70).
+(layers.py:93-134), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb (network.py:173-187) and the generator loss's
+random multiplier and feature-matching term (losses.py:46, 62-70).
 
 Fixture ``variants.npz`` (``tools/make_golden_variants.py``): per case one critic and one generator loss evaluation
 of the imported reference, 8 samples, in fp64 and fp32."""
@@ -35,6 +35,10 @@ CASES = {
     "batch_norm": dict(generator=dict(act_norm="batch")),
     "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True)),
     "split_z": dict(generator=dict(act_norm="batch", z_to_bn=True, split_z=True)),
+    "to_rgb_sngan": dict(generator=dict(to_rgb_mode="sngan")),
+    "to_rgb_sagan": dict(generator=dict(to_rgb_mode="sagan")),
+    "to_rgb_biggan": dict(generator=dict(to_rgb_mode="biggan")),
+    "to_rgb_biggan_plain": dict(generator=dict(to_rgb_mode="biggan", no_tanh=True)),
 }
 
 
@@ -58,7 +62,8 @@ def _oracle_config(case):
     from oracle import ref_cpu as O
     kw = {}
     for src, keys in ((case.get("shared", {}), ("residual", "act_alpha", "deep", "self_attention_layers")),
-                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z")),
+                      (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z",
+                                                   "to_rgb_mode")),
                       (case.get("discriminator", {}), ("input_to_all_layers", "group_size"))):
         kw.update({k: src[k] for k in keys if k in src})
     if "act_norm" in case.get("generator", {}):
@@ -118,11 +123,13 @@ def test_oracle_matches_reference(name):
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
     for kw in (dict(generator=dict(per_channel_noise=True)), dict(generator=dict(spectral=True)),
-               dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10)), dict(generator=dict(to_rgb_mode="sagan"))):
+               dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
         config.build_models(1, generator=dict(rgb_generation_mode="median"))
+    with pytest.raises(ValueError):
+        config.build_models(1, generator=dict(to_rgb_mode="stylegan"))
 
 
 @pytest.mark.gpu
@@ -409,5 +416,24 @@ def test_graph_trainer_with_batch_norm(dev):
         base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
         graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
         E._same_trajectory(base, graphed, "graph replay, batch norm", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sagan", "biggan"])
+def test_graph_trainer_with_other_to_rgb(dev, mode):
+    """The 'sagan' (two layers) and 'biggan' (batch norm, ReLU, k = 3 conv) forms of to_rgb under the graph trainer:
+    the trajectory is the eager trainer's (with a batch norm the fakes are made per critic iteration)."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models=dict(generator=dict(to_rgb_mode=mode)))
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        E._same_trajectory(base, graphed, f"graph replay, to_rgb {mode}", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")

@@ -5,8 +5,8 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
 separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
-modulated by the latent), and the generator loss's random multiplier and
-feature-matching term.  Every case records one critic and one
+modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, and the generator loss's random multiplier
+and feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
 
@@ -46,6 +46,11 @@ CASES = {
     "batch_norm": dict(generator=dict(act_norm="batch"), depth=3, alpha=0.6),
     "batch_norm_z": dict(generator=dict(act_norm="batch", z_to_bn=True), depth=2, alpha=1.0),
     "split_z": dict(generator=dict(act_norm="batch", z_to_bn=True, split_z=True), depth=2, alpha=0.5),
+    # the other forms of the layer that turns features into the signal
+    "to_rgb_sngan": dict(generator=dict(to_rgb_mode="sngan"), depth=2, alpha=0.5),
+    "to_rgb_sagan": dict(generator=dict(to_rgb_mode="sagan"), depth=3, alpha=1.0),
+    "to_rgb_biggan": dict(generator=dict(to_rgb_mode="biggan"), depth=2, alpha=0.7),
+    "to_rgb_biggan_plain": dict(generator=dict(to_rgb_mode="biggan", no_tanh=True), depth=1, alpha=1.0),
 }
 
 
@@ -60,7 +65,7 @@ def oracle_config(case):
         kw["deep"] = sh["deep"]
     if "self_attention_layers" in sh:
         kw["self_attention_layers"] = tuple(sh["self_attention_layers"])
-    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z"):
+    for k in ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z", "to_rgb_mode"):
         if k in ge:
             kw[k] = ge[k]
     if "act_norm" in ge:
