@@ -26,6 +26,7 @@ int check_launch(const char* what);
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // a vector load from a 4-byte aligned address
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- activation storage types -----------------------------------------------------------------------

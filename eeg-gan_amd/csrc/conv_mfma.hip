@@ -188,11 +188,18 @@ struct XStage {
 //   prefetch wants it known at compile time: a branch around the mask loads makes the load counts the waits
 //   are computed from path-dependent, and the waits conservative.
 //   BF (FULL, SPLIT = 1): the activations (x, mask_y, y, act_aux) are bfloat16 in memory (bf16 storage mode).
+//   FULL tolerates Cout % CT != 0: the last channel tile stages the last weight row again for its missing rows and
+//   stores only the rows that exist (the input gradient of a layer with 256 + 1 input channels).
+//   RAGC (FULL, SPLIT = 3): Cin = 32 n + r with a few left-over channels r.  The main loop takes the 32 n channels
+//   (weight rows are then not 16-byte aligned: their vector loads are declared 4-byte aligned); the r channels'
+//   terms are added in the epilogue with plain fp32 arithmetic -- the layer behind MinibatchStddev has 256 + 1 input
+//   channels, and the generic predicated form took 2.5x the time of the 256-channel layers beside it.
 template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, int KS, int SPLIT = 0, int MASK = -1,
-          bool BF = false, int NTHR = 64 * WM * WN * KS>
+          bool BF = false, bool RAGC = false, int NTHR = 64 * WM * WN * KS>
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
     static_assert(!BF || (FULL && VEC && SPLIT == 1), "bf16 storage: predicate-free form with bf16 products");
+    static_assert(!RAGC || (FULL && VEC && SPLIT == 3 && !BF), "left-over input channels: predicate-free form, fp32 products");
     typedef typename ActT<BF>::T AT;
     typedef typename ActT<BF>::raw4 R4;
     typedef typename ActT<BF>::raw1 R1;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     const int tiles_x = (a.NS + NT - 1) / NT;
     const int tiles_y = (a.Cout + CT - 1) / CT;
     const int ntiles = tiles_x * tiles_y;
-    const int nchunks = (a.Cin + CK - 1) / CK;
+    const int nchunks = RAGC ? a.Cin / CK : (a.Cin + CK - 1) / CK;
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nsteps = my_tiles * nchunks;
     if (nsteps <= 0) return;
@@ -312,7 +319,10 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
         }
         if (FULL) {
 #pragma unroll
-            for (int i = 0; i < WV; ++i) fw[i] = live ? a.w + ((long long)(p_co0 + w_row[i]) * a.Cin) * K + 4 * w_q[i] : a.w;
+            for (int i = 0; i < WV; ++i) {
+                const int co = p_co0 + w_row[i] < a.Cout ? p_co0 + w_row[i] : a.Cout - 1;  // (a partly filled last tile)
+                fw[i] = live ? a.w + ((long long)co * a.Cin) * K + 4 * w_q[i] : a.w;
+            }
             fx = X0 + (x_ok ? x_off : 0);
             fh = X0 + (h_ok ? h_off : 0);
             if (has_mask) {
@@ -350,7 +360,10 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const int wo = ci0 * K;
             const long long xo = (long long)ci0 * a.T;
 #pragma unroll
-            for (int i = 0; i < WV; ++i) wv[i] = *reinterpret_cast<const f32x4*>(fw[i] + wo);
+            for (int i = 0; i < WV; ++i) {
+                if constexpr (RAGC) wv[i] = *reinterpret_cast<const f32x4u*>(fw[i] + wo);
+                else wv[i] = *reinterpret_cast<const f32x4*>(fw[i] + wo);
+            }
 #pragma unroll
             for (int i = 0; i < XV; ++i) {
                 const long long o = x_ok ? xo + (long long)(i * XROWS) * a.T : 0;
@@ -790,6 +803,34 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             f32x4 v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = acc[i][n][4 * q + e] + bb;
+                            if constexpr (RAGC) {
+                                // the left-over input channels: out[t] += sum_j w[j] x[t + j - 1], six inputs per run
+                                // of four outputs (all loads from valid addresses, dropped by selects)
+                                for (int c = nchunks * CK; c < a.Cin; ++c) {
+                                    const float* wp = a.w + ((long long)cc * a.Cin + c) * 3;
+                                    const float w0 = wp[0] * a.in_scale, w1 = wp[1] * a.in_scale, w2 = wp[2] * a.in_scale;
+                                    const long long xrow = ((long long)bc * a.Cin + c) * a.T;
+                                    const int tt = ok ? t : 0;
+                                    const bool lo = ok && tt > 0, hi = ok && tt + 4 < a.T;
+                                    f32x4 xm = *reinterpret_cast<const f32x4*>(a.x + xrow + tt);
+                                    float xl = a.x[xrow + (lo ? tt - 1 : 0)], xh = a.x[xrow + (hi ? tt + 4 : 0)];
+                                    if (has_mask) {
+                                        const float d = a.mask_drop ? a.mask_drop[bc * a.Cin + c] : 1.f;
+                                        const f32x4 mm = *reinterpret_cast<const f32x4*>(a.mask_y + xrow + tt);
+                                        const float ml = a.mask_y[xrow + (lo ? tt - 1 : 0)], mh = a.mask_y[xrow + (hi ? tt + 4 : 0)];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) xm[e] *= mm[e] > 0.f ? d : d * a.mask_slope;
+                                        xl *= ml > 0.f ? d : d * a.mask_slope;
+                                        xh *= mh > 0.f ? d : d * a.mask_slope;
+                                    }
+                                    xl = lo ? xl : 0.f;
+                                    xh = hi ? xh : 0.f;
+                                    v[0] += w0 * xl + w1 * xm[0] + w2 * xm[1];
+                                    v[1] += w0 * xm[0] + w1 * xm[1] + w2 * xm[2];
+                                    v[2] += w0 * xm[1] + w1 * xm[2] + w2 * xm[3];
+                                    v[3] += w0 * xm[2] + w1 * xm[3] + w2 * xh;
+                                }
+                            }
                             if (ACT == EEGGAN_ACT_LRELU) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_param;
@@ -901,11 +942,11 @@ int num_cus() {
 namespace {
 
 template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL = false, int KS = 1, int SPLIT = 0, int MASK = -1,
-          bool BF = false>
+          bool BF = false, bool RAGC = false>
 int launch_fwd(const ConvArgs& a, hipStream_t st) {
     constexpr int wld = SPLIT ? 3 * (CK * K * 2 + 16) / 4 : CK * K + 4;  // floats per weight row (the kernel's WLD)
     constexpr size_t lds = ((size_t)2 * (CT * wld + CK * NT * SUB) + (KS > 1 ? 64 * 16 * (CT / 32) * NT : 0)) * sizeof(float);
-    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK, BF>;
+    auto kernel = &conv_fwd_kernel<K, CT, NT, CK, WM, WN, VEC, FULL, KS, SPLIT, MASK, BF, RAGC>;
     // resident workgroups per CU; also opts in to > 64 KiB of dynamic LDS (once per device)
     static std::atomic<int> per_cu_dev[MAX_DEVICES];
     std::atomic<int>& slot = per_cu_dev[current_device()];
@@ -935,6 +976,16 @@ int launch_fwd(const ConvArgs& a, hipStream_t st) {
 // one-subtile tile whose four waves split the reduction, small enough in LDS for two workgroups per
 // CU.  (Measured in the captured training step against a two-subtile tile without the split:
 // +3.4 % steps/s; the T = 32 layers alone run twice as fast.)
+// (comparison switch: EEGGAN_CONV_RAGGED=0 sends layers with 32 n + r input channels, or a partly filled last tile of
+// output channels, to the generic predicated kernel)
+static bool ragged_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("EEGGAN_CONV_RAGGED");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <int K>
 int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
     const long long ns = a.NS;
@@ -980,12 +1031,22 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
             return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 0, true>(a, st)
                        : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 0, true>(a, st);
         }
-        if (full && pieces == 3) {
+        // (a last channel tile that is only partly filled is fine for these kernels when it wastes little)
+        const bool full_cin = a.Cin % 32 == 0 && a.T % 32 == 0 && a.Cout >= 128;
+        if ((full || (full_cin && ragged_enabled())) && pieces == 3) {
             if (a.mask_y)
                 return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 1>(a, st)
                            : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 1>(a, st);
             return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 0>(a, st)
                        : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 0>(a, st);
+        }
+        // a few input channels beyond a multiple of 32 (256 + 1 behind MinibatchStddev): added in the epilogue
+        if (pieces == 3 && ragged_enabled() && a.Cin > 64 && a.Cin % 32 != 0 && a.Cin % 32 <= 4 && a.Cout % 64 == 0 && a.T % 32 == 0) {
+            if (a.mask_y)
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 1, false, true>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 1, false, true>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 0, false, true>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 0, false, true>(a, st);
         }
         if (full && pieces == 1) {
             if (a.mask_y)

@@ -97,6 +97,48 @@ def test_conv_fwd_dgrad_wgrad(dev, B, Cin, Cout, T, K):
     assert rel(om, conv_ref(q, w, None, scale, pad) * mask) < TOL
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T", [(4, 257, 256, 32), (64, 257, 256, 32), (3, 258, 128, 64), (40, 131, 192, 32),
+                                          (4, 256, 257, 32), (64, 256, 257, 32), (5, 128, 130, 96), (520, 257, 256, 32),
+                                          (520, 256, 257, 32)])
+def test_conv_ragged_channels(dev, B, Cin, Cout, T):
+    """k = 3 layers with a few input channels beyond a multiple of 32 (the layer behind MinibatchStddev: 256 + 1; the
+    left-over channels' terms are added in the epilogue) or with a partly filled last tile of output channels (its
+    input gradient), on the predicate-free kernels: every epilogue, and the fused input mask, small and large batches."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + Cin * 7 + Cout * 13 + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, 3, generator=g)
+    b = torch.randn(Cout, generator=g)
+    drop = torch.rand(B, Cout, generator=g) + 0.5
+    my = torch.randn(B, Cin, T, generator=g)
+    md = torch.rand(B, Cin, generator=g) + 0.5
+    aux = torch.randn(B, Cout, T, generator=g)
+    xd, wd, bd, dd, myd, mdd, auxd = (t.to(dev) for t in (x, w, b, drop, my, md, aux))
+    sel = sorted({0, 1, B // 2, B - 2, B - 1})
+    scale = 0.37
+    y = ops.conv1d_raw(xd, wd, bd, dd, in_scale=scale, act=1, act_param=0.2)
+    assert rel(y[sel], conv_ref(x[sel], w, b, scale, 1, drop[sel], "lrelu")) < TOL
+    y = ops.conv1d_raw(xd, wd, bd, None, in_scale=scale)
+    assert rel(y[sel], conv_ref(x[sel], w, b, scale, 1)) < TOL
+    xm = x[sel].double() * torch.where(my[sel] > 0, 1.0, 0.2).double() * md[sel].double()[:, :, None]
+    ref = F.conv1d(xm * scale, w.double(), None, padding=1)
+    y = ops.conv1d_raw(xd, wd, None, None, in_scale=scale, mask_y=myd, mask_drop=mdd, mask_slope=0.2)
+    assert rel(y[sel], ref) < TOL
+    y = ops.conv1d_raw(xd, wd, None, None, in_scale=scale, mask_y=myd, mask_slope=0.2)
+    xm1 = x[sel].double() * torch.where(my[sel] > 0, 1.0, 0.2).double()
+    assert rel(y[sel], F.conv1d(xm1 * scale, w.double(), None, padding=1)) < TOL
+    refm = ref * torch.where(aux[sel] > 0, 1.0, 0.2).double() * drop[sel].double()[:, :, None]
+    y = ops.conv1d_raw(xd, wd, None, dd, in_scale=scale, mask_y=myd, mask_drop=mdd, mask_slope=0.2, act=3, act_param=0.2,
+                       act_aux=auxd)
+    assert rel(y[sel], refm) < TOL
+    # the left-over channels alone must be right too: weights that are zero everywhere else
+    if Cin % 32:
+        w2 = w.clone()
+        w2[:, :Cin - Cin % 32] = 0
+        y = ops.conv1d_raw(xd, w2.to(dev), None, None, in_scale=scale)
+        assert rel(y[sel], conv_ref(x[sel], w2, None, scale, 1)) < TOL
+
+
 @pytest.mark.parametrize("Cin,Cout", [(5, 64), (64, 5), (8, 8)])
 def test_conv_thin_large_batch(dev, Cin, Cout):
     """1x1 convs with at most 8 channels on one side run a bandwidth-bound kernel of their own once the
