@@ -752,6 +752,63 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
             const int co0 = ty * CT;
             const bool full = co0 + CT <= a.Cout;
             const bool has_bias = a.bias != nullptr, has_drop = a.drop != nullptr;
+            if constexpr (RAGC) {
+                // The left-over input channels, added to the accumulators of the waves that will run the epilogue:
+                // out[t] += sum_j w[j] x[t + j - 1], six inputs per run of four outputs.  All loads come first (from
+                // valid addresses, dropped by selects) and nothing is stored in between: one trip to memory.
+                if (KS == 1 || kid == 0) {
+#pragma unroll
+                    for (int n = 0; n < RN; ++n) {
+                        const int sub = tx * NT + wn * RN + n;
+                        const int b = sub / a.ST;
+                        const int t0 = (sub - b * a.ST) * 32 + 4 * h;
+                        const bool sok = sub < a.NS;
+                        const int bc = sok ? b : 0;
+#pragma unroll
+                        for (int i = 0; i < RM; ++i) {
+                            const int co = co0 + (wm * RM + i) * 32 + l31;
+                            const int cc = co < a.Cout ? co : 0;
+                            for (int c = nchunks * CK; c < a.Cin; ++c) {
+                                const float* wp = a.w + ((long long)cc * a.Cin + c) * 3;
+                                const float w0 = wp[0] * a.in_scale, w1 = wp[1] * a.in_scale, w2 = wp[2] * a.in_scale;
+                                const long long xrow = ((long long)bc * a.Cin + c) * a.T;
+                                const float d = (has_mask && a.mask_drop) ? a.mask_drop[bc * a.Cin + c] : 1.f;
+                                f32x4 xm[4], mm[4];
+                                float xl[4], xh[4], ml[4], mh[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int t = sok ? t0 + 8 * q : 0;
+                                    const bool lo = t > 0, hi = t + 4 < a.T;
+                                    xm[q] = *reinterpret_cast<const f32x4*>(a.x + xrow + t);
+                                    xl[q] = a.x[xrow + (lo ? t - 1 : 0)];
+                                    xh[q] = a.x[xrow + (hi ? t + 4 : 0)];
+                                    if (has_mask) {
+                                        mm[q] = *reinterpret_cast<const f32x4*>(a.mask_y + xrow + t);
+                                        ml[q] = a.mask_y[xrow + (lo ? t - 1 : 0)];
+                                        mh[q] = a.mask_y[xrow + (hi ? t + 4 : 0)];
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int t = sok ? t0 + 8 * q : 0;
+                                    const bool lo = t > 0, hi = t + 4 < a.T;
+                                    if (has_mask) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) xm[q][e] *= mm[q][e] > 0.f ? d : d * a.mask_slope;
+                                        xl[q] *= ml[q] > 0.f ? d : d * a.mask_slope;
+                                        xh[q] *= mh[q] > 0.f ? d : d * a.mask_slope;
+                                    }
+                                    const float l = lo ? xl[q] : 0.f, r = hi ? xh[q] : 0.f;
+                                    acc[i][n][4 * q + 0] += w0 * l + w1 * xm[q][0] + w2 * xm[q][1];
+                                    acc[i][n][4 * q + 1] += w0 * xm[q][0] + w1 * xm[q][1] + w2 * xm[q][2];
+                                    acc[i][n][4 * q + 2] += w0 * xm[q][1] + w1 * xm[q][2] + w2 * xm[q][3];
+                                    acc[i][n][4 * q + 3] += w0 * xm[q][2] + w1 * xm[q][3] + w2 * r;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             if (KS > 1) {
                 // waves kid > 0 hand their partial sums to the kid = 0 wave of the same (wm, wn)
                 float* red = smem + 2 * BUF + ((wave % (WM * WN)) * RM * RN) * 16 * 64 + lane;
@@ -803,34 +860,6 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             f32x4 v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = acc[i][n][4 * q + e] + bb;
-                            if constexpr (RAGC) {
-                                // the left-over input channels: out[t] += sum_j w[j] x[t + j - 1], six inputs per run
-                                // of four outputs (all loads from valid addresses, dropped by selects)
-                                for (int c = nchunks * CK; c < a.Cin; ++c) {
-                                    const float* wp = a.w + ((long long)cc * a.Cin + c) * 3;
-                                    const float w0 = wp[0] * a.in_scale, w1 = wp[1] * a.in_scale, w2 = wp[2] * a.in_scale;
-                                    const long long xrow = ((long long)bc * a.Cin + c) * a.T;
-                                    const int tt = ok ? t : 0;
-                                    const bool lo = ok && tt > 0, hi = ok && tt + 4 < a.T;
-                                    f32x4 xm = *reinterpret_cast<const f32x4*>(a.x + xrow + tt);
-                                    float xl = a.x[xrow + (lo ? tt - 1 : 0)], xh = a.x[xrow + (hi ? tt + 4 : 0)];
-                                    if (has_mask) {
-                                        const float d = a.mask_drop ? a.mask_drop[bc * a.Cin + c] : 1.f;
-                                        const f32x4 mm = *reinterpret_cast<const f32x4*>(a.mask_y + xrow + tt);
-                                        const float ml = a.mask_y[xrow + (lo ? tt - 1 : 0)], mh = a.mask_y[xrow + (hi ? tt + 4 : 0)];
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) xm[e] *= mm[e] > 0.f ? d : d * a.mask_slope;
-                                        xl *= ml > 0.f ? d : d * a.mask_slope;
-                                        xh *= mh > 0.f ? d : d * a.mask_slope;
-                                    }
-                                    xl = lo ? xl : 0.f;
-                                    xh = hi ? xh : 0.f;
-                                    v[0] += w0 * xl + w1 * xm[0] + w2 * xm[1];
-                                    v[1] += w0 * xm[0] + w1 * xm[1] + w2 * xm[2];
-                                    v[2] += w0 * xm[1] + w1 * xm[2] + w2 * xm[3];
-                                    v[3] += w0 * xm[2] + w1 * xm[3] + w2 * xh;
-                                }
-                            }
                             if (ACT == EEGGAN_ACT_LRELU) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_param;
