@@ -72,6 +72,8 @@ SIGNATURES = {
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_feature_match_fwd": (_i, [_f, _f, _f, _f, _i, _i, _st]),
     "eeggan_feature_match_bwd": (_i, [_f, _f, _f, _i, _i, _st]),
+    "eeggan_spectral_norm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _i, _st]),
+    "eeggan_spectral_norm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _st]),
     "eeggan_bn_lrelu_drop_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _fl, _fl, _fl, _i, _st]),
     "eeggan_bn_lrelu_drop_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
     "eeggan_bmm": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _fl, _st]),

@@ -318,7 +318,9 @@ class GraphedTrainer(Trainer):
         d_loss_fn = self.d_loss
         self._fakes_call = self._zall = self._fake = None
         # (a generator with batch norm layers couples the samples of a pass: its fakes are made per iteration)
-        per_sample = not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in self.generator.modules())
+        # (a spectral norm's power iteration runs once per forward: as many generator passes as the eager trainer)
+        per_sample = not any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) or getattr(m, "spectral", False)
+                             for m in self.generator.modules())
         if self.batch_fakes and per_sample and self.d_training_repeats > 1 and _accepts(self.d_loss, "fake"):
             self._zall = z.repeat(self.d_training_repeats, *([1] * (z.dim() - 1)))
 
@@ -353,7 +355,10 @@ class GraphedTrainer(Trainer):
             return first, bucket, GraphedCall(lambda: sync.apply(optimizer, bucket))
 
         self._d_parts = None
-        if self.split_critic and self._fake is not None and _accepts(self.d_loss, "part"):
+        # (with spectral norm every critic pass advances the layers' power-iteration vectors in place: passes side by
+        # side on two streams would race on them)
+        spectral_d = any(getattr(m, "spectral", False) for m in self.discriminator.modules())
+        if self.split_critic and not spectral_d and self._fake is not None and _accepts(self.d_loss, "part"):
             from .losses import PartsUnavailable
             try:
                 self._d_parts = _SplitCriticIteration(self, d_loss_fn, sync, bucketed, parts=self.critic_chains)

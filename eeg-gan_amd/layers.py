@@ -300,9 +300,9 @@ class EqualizedConv1d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, padding, spectral, equalized, init, act_alpha, bias,
                  groups, stride):
         super().__init__()
-        if spectral or stride != 1 or (groups != 1 and not (groups == in_channels == out_channels)):
-            raise NotImplementedError("EqualizedConv1d: spectral norm, strides and groups other than 1 or the channel "
-                                      "count (depthwise) are not supported")
+        if stride != 1 or (groups != 1 and not (groups == in_channels == out_channels)):
+            raise NotImplementedError("EqualizedConv1d: strides and groups other than 1 or the channel count (depthwise) "
+                                      "are not supported")
         self.depthwise = groups != 1
         self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias,
                               groups=groups)
@@ -321,7 +321,25 @@ class EqualizedConv1d(nn.Module):
             w.copy_(w / self.scale)
         self.kernel_size = kernel_size
         self.padding = padding
-        self._flip = ops.FlipCache(self.conv.weight)
+        self.spectral = bool(spectral)
+        if spectral:
+            # (layers.py:170-171) torch's own registration: the parameter becomes ``weight_orig`` and the vectors of
+            # the power iteration the buffers ``weight_u`` / ``weight_v``, drawn from the same random stream as the
+            # reference's.  Its forward hook never runs (the container's forward is never called): ``weight()`` does
+            # the iteration and the normalisation with the library's kernels.
+            self.conv = nn.utils.spectral_norm(self.conv)
+            self._flip = None  # the normalised weight is a new tensor at every forward: its flipped view is not cached
+        else:
+            self._flip = ops.FlipCache(self.conv.weight)
+
+    def weight(self):
+        """The weight the conv runs with: the parameter, or with spectral norm the parameter over its largest singular
+        value as one power iteration per forward in training mode estimates it."""
+        if not self.spectral:
+            return self.conv.weight
+        c = self.conv
+        w, self.last_sigma = ops.spectral_norm(c.weight_orig, c.weight_u, c.weight_v, 1e-12, self.training)
+        return w
 
     def kind(self, x):
         k, pad = self.kernel_size, self.padding
@@ -335,10 +353,10 @@ class EqualizedConv1d(nn.Module):
 
     def forward(self, x):
         if self.depthwise:
-            return ops.dwconv1d(x, self.conv.weight, self.conv.bias, self.scale, self.padding)
+            return ops.dwconv1d(x, self.weight(), self.conv.bias, self.scale, self.padding)
         if self.kind(x) != "same":
             raise NotImplementedError("a bare full-length conv is only available fused inside GeneralConv")
-        return ops.conv1d(x, self.conv.weight, self.conv.bias, None, self.scale, ACT_NONE, flip=self._flip)
+        return ops.conv1d(x, self.weight(), self.conv.bias, None, self.scale, ACT_NONE, flip=self._flip)
 
 
 class EqualizedSeparableConv1d(nn.Module):
@@ -422,7 +440,7 @@ class GeneralConv(nn.Module):
             # ordinary same-padded layer with this layer's epilogue
             x = c.net[0](x)
             c = c.net[1]
-        w, b, s = c.conv.weight, c.conv.bias, c.scale
+        w, b, s = c.weight(), c.conv.bias, c.scale
         kind = c.kind(x)
         slope = float(max(self.act_alpha, 0.0))
         if _tanh_scale is not None:  # to_rgb: linear conv + tanh(scale * .)

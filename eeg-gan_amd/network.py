@@ -11,7 +11,8 @@ the critic's ``input_to_all_layers``
 (network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553), and in the
 generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322)
 and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
-``to_rgb_mode`` (network.py:173-187).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+``to_rgb_mode`` (network.py:173-187), and ``spectral`` in either network (spectral norm of every conv weight,
+layers.py:170-171).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -111,7 +112,6 @@ class Generator(nn.Module):
                  act_norm="pixel", conv_only=False, shared_embedding_size=32, normalize_latents=True,
                  rgb_generation_mode="pggan"):
         super().__init__()
-        _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not conv_only, "conditioning/conv_only")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         _require(not per_channel_noise, "per_channel_noise")
@@ -270,7 +270,6 @@ class Discriminator(nn.Module):
                  temporal_groups_per_window=1, conv_only=False, input_to_all_layers=False, initial_sampling_rate=1.0,
                  sinc=False):
         super().__init__()
-        _require(not spectral, "spectral norm")
         _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)

@@ -1026,6 +1026,49 @@ def bn_act(c, drop, gamma, beta, gmod, bmod, run_mean, run_var, slope, eps, mome
                         bool(train))
 
 
+class _SpectralNorm(Function):
+    """w_orig / sigma with sigma = u^T W v of the weight as a matrix [output channels, rest], after one power iteration
+    on the module's vectors ``u`` and ``v`` (in place) when ``iterate`` (torch.nn.utils.spectral_norm's arithmetic; the
+    vectors are constants of the backward).  First-order differentiable: what is differentiated twice under the
+    gradient penalty is the conv, with respect to the normalised weight."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, eps, iterate):
+        w_orig = _chk(w_orig, "spectral norm weight")
+        rows = w_orig.shape[0]
+        cols = w_orig.numel() // rows
+        for t, n, what in ((u, rows, "u"), (v, cols, "v")):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                raise RuntimeError(f"spectral norm: {what} must be a contiguous float32 device vector of {n} elements")
+        w_sn = torch.empty_like(w_orig)
+        u_used, v_used = torch.empty_like(u), torch.empty_like(v)
+        sigma = torch.empty((1,), device=w_orig.device, dtype=torch.float32)
+        scratch = torch.empty((rows,), device=w_orig.device, dtype=torch.float32)
+        call("eeggan_spectral_norm_fwd", w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), w_sn.data_ptr(), u_used.data_ptr(),
+             v_used.data_ptr(), sigma.data_ptr(), scratch.data_ptr(), rows, cols, float(eps), int(iterate), _stream())
+        ctx.save_for_backward(w_sn, u_used, v_used, sigma)
+        ctx.mark_non_differentiable(sigma)
+        return w_sn, sigma
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _):
+        w_sn, u_used, v_used, sigma = ctx.saved_tensors
+        g = _chk(g, "spectral norm grad")
+        rows = w_sn.shape[0]
+        cols = w_sn.numel() // rows
+        out = torch.empty_like(w_sn)
+        scratch = torch.empty((1,), device=w_sn.device, dtype=torch.float32)
+        call("eeggan_spectral_norm_bwd", g.data_ptr(), w_sn.data_ptr(), u_used.data_ptr(), v_used.data_ptr(), sigma.data_ptr(),
+             scratch.data_ptr(), out.data_ptr(), rows, cols, _stream())
+        return out, None, None, None, None
+
+
+def spectral_norm(w_orig, u, v, eps=1e-12, iterate=True):
+    """(normalised weight, sigma [1])."""
+    return _SpectralNorm.apply(w_orig, u, v, float(eps), bool(iterate))
+
+
 class _ScaledTanh(Function):
     """y = tanh(scale * x) on its own (on the training path the to_rgb conv applies it as its epilogue)."""
 

@@ -310,6 +310,17 @@ int eeggan_bn_lrelu_drop_bwd(const float* gy, const float* y, const float* c, co
                              float* g_gamma, float* g_beta, float* g_gmod, float* g_bmod, int B, int C, int T, float slope,
                              int train, void* stream);
 
+/* ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm as layers.py:170-171 and network.py:520-521
+ * apply it): the weight as a matrix W [rows = output channels, cols = the other dimensions]. -------------------- */
+/* power_iteration != 0 (training): v <- normalize(W^T u), u <- normalize(W v) in place (normalize(x) = x / max(|x|, eps));
+ * then sigma = u^T W v and w_sn = w_orig / sigma.  u [rows] and v [cols] are the module's vectors; u_used / v_used
+ * receive the vectors sigma was computed with (for the backward); sigma: one float; scratch: rows floats. */
+int eeggan_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* w_sn, float* u_used, float* v_used,
+                             float* sigma, float* scratch, int rows, int cols, float eps, int power_iteration, void* stream);
+/* g_orig = (g_sn - <g_sn, w_sn> u v^T) / sigma: u and v are constants of the forward.  scratch: one float. */
+int eeggan_spectral_norm_bwd(const float* g_sn, const float* w_sn, const float* u_used, const float* v_used,
+                             const float* sigma, float* scratch, float* g_orig, int rows, int cols, void* stream);
+
 /* ---- self attention (SelfAttention, layers.py:41-64): out = gamma * Wf (value P) + x with
  * P = softmax over dim 1 of key^T query, key / value max-pooled by 4 along time.  The 1x1 convs are eeggan_conv1d;
  * the rest is made of the entry points below (float32 tensors). ------------------------------------------------ */

@@ -194,6 +194,27 @@ def gdrop(x, strength: float, src: DropSource):
     return x * torch.from_numpy(r).to(x.dtype)
 
 
+def layer_weight(params, prefix: str, training: bool = True, eps: float = 1e-12):
+    """The weight of the conv at ``prefix`` (an nn.Conv1d's path).  With spectral norm (layers.py:170-171:
+    torch.nn.utils.spectral_norm, training mode) the parameter is ``weight_orig`` and every call does one power
+    iteration on the stored vectors, in place and without gradient -- v = normalize(W^T u), u = normalize(W v) on the
+    weight as a matrix [output channels, rest] -- then divides by sigma = u^T W v (the vectors as constants)."""
+    if f"{prefix}.weight_orig" not in params:
+        return params[f"{prefix}.weight"]
+    w, u, v = params[f"{prefix}.weight_orig"], params[f"{prefix}.weight_u"], params[f"{prefix}.weight_v"]
+    wm = w.reshape(w.shape[0], -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+    u, v = u.detach().clone(), v.detach().clone()
+    return w / torch.dot(u, torch.mv(wm, v))
+
+
+def has_layer(params, prefix: str) -> bool:
+    return f"{prefix}.weight" in params or f"{prefix}.weight_orig" in params
+
+
 def conditional_batch_norm(x, params, scales, prefix: str, z=None):
     """ConditionalBatchNorm.forward in training mode, layers.py:117-134: statistics of the batch over (batch, time);
     'BN' mode (affine normaliser) when the layer has no modulation network, else 'SM': a normaliser without affine
@@ -201,7 +222,7 @@ def conditional_batch_norm(x, params, scales, prefix: str, z=None):
     between, layers.py:107-111) on the latent [B, latent, 1], repeated over time."""
     out = F.batch_norm(x, None, None, params.get(f"{prefix}.normalizer.weight"), params.get(f"{prefix}.normalizer.bias"),
                        training=True, eps=1e-5)
-    if f"{prefix}.embed.0.conv.conv.weight" not in params:
+    if not has_layer(params, f"{prefix}.embed.0.conv.conv"):
         return out
     e = general_conv(z, params, scales, f"{prefix}.embed.0", act_alpha=0.0)
     e = general_conv(e, params, scales, f"{prefix}.embed.1", act_alpha=-1)
@@ -214,17 +235,17 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
                  src: Optional[DropSource] = None, z=None):
     """layers.py:207-213 for the default options: conv -> LeakyReLU ->
     (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
-    if f"{path}.conv.net.0.conv.weight" in params:
+    if has_layer(params, f"{path}.conv.net.0.conv"):
         # separable layer (layers.py:137-147): a depthwise conv with its own scale and bias and the layer's padding,
         # then a 1x1 conv; activation, norm and multiplier follow the pair
-        w0, b0 = params[f"{path}.conv.net.0.conv.weight"], params[f"{path}.conv.net.0.conv.bias"]
+        w0, b0 = layer_weight(params, f"{path}.conv.net.0.conv"), params[f"{path}.conv.net.0.conv.bias"]
         k = w0.shape[2]
         pad = (k - 1) // 2 if pad is None else pad
         h = F.conv1d(x * scales[f"{path}.conv.net.0"], w0, b0, padding=pad, groups=w0.shape[0])
-        h = equalized_conv1d(h, params[f"{path}.conv.net.1.conv.weight"], params[f"{path}.conv.net.1.conv.bias"],
+        h = equalized_conv1d(h, layer_weight(params, f"{path}.conv.net.1.conv"), params[f"{path}.conv.net.1.conv.bias"],
                              scales[f"{path}.conv.net.1"], 0)
     else:
-        w = params[f"{path}.conv.conv.weight"]
+        w = layer_weight(params, f"{path}.conv.conv")
         b = params.get(f"{path}.conv.conv.bias")  # (absent: a layer built with bias=False)
         k = w.shape[2]
         pad = (k - 1) // 2 if pad is None else pad
@@ -353,7 +374,7 @@ def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", f
 
 def _skip(params, scales, path, x):
     """The skip of a residual block: the identity when the block keeps the channel count, a linear 1x1 conv otherwise."""
-    if f"{path}.conv.conv.weight" in params:
+    if has_layer(params, f"{path}.conv.conv"):
         return general_conv(x, params, scales, path, act_alpha=-1)
     return x
 
@@ -403,7 +424,7 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
         h = general_conv(h, params, scales, f"blocks.{pos}.net.2", **ls)
         h = general_conv(h, params, scales, f"blocks.{pos}.net.3", **ls)
         skip = f"blocks.{pos}.residual.net"
-        if f"{skip}.conv.conv.weight" in params:
+        if has_layer(params, f"{skip}.conv.conv"):
             return h + torch.cat([x, general_conv(x, params, scales, skip, act_alpha=-1)], dim=1)
         return h + x
     if cfg.residual:  # network.py:431-438, 447-448

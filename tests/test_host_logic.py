@@ -46,7 +46,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Discriminator(**{**kw, "num_classes": 10}, **config.DISCRIMINATOR_KWARGS)
     with pytest.raises(NotImplementedError):
-        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "spectral": True})
+        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "conv_only": True})
 
 
 def test_depth_manager_schedule():

@@ -2,7 +2,7 @@
 generator's 'residual' / 'mean' signal modes (332-349), the critic's input at every stage (533-549), plain layers
 (ReLU, no equalization, xavier init, to_rgb without tanh, latents not normalised, no MinibatchStddev), separable
 layers, deep blocks, self attention (layers.py:41-64), batch norm in the generator plain and modulated by the latent
-(layers.py:93-134), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb (network.py:173-187) and the generator loss's
+(layers.py:93-134), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb (network.py:173-187), spectral norm (layers.py:170-171) and the generator loss's
 random multiplier and feature-matching term (losses.py:46, 62-70).
 
 Fixture ``variants.npz`` (``tools/make_golden_variants.py``): per case one critic and one generator loss evaluation
@@ -39,6 +39,10 @@ CASES = {
     "to_rgb_sagan": dict(generator=dict(to_rgb_mode="sagan")),
     "to_rgb_biggan": dict(generator=dict(to_rgb_mode="biggan")),
     "to_rgb_biggan_plain": dict(generator=dict(to_rgb_mode="biggan", no_tanh=True)),
+    "spectral_d": dict(shared=dict(equalized=False), discriminator=dict(spectral=True)),
+    "spectral_g": dict(shared=dict(equalized=False), generator=dict(spectral=True)),
+    "spectral_both": dict(shared=dict(equalized=False, self_attention_layers=[1]), generator=dict(spectral=True),
+                          discriminator=dict(spectral=True), gamma=0.3),
 }
 
 
@@ -122,7 +126,7 @@ def test_oracle_matches_reference(name):
 
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
-    for kw in (dict(generator=dict(per_channel_noise=True)), dict(generator=dict(spectral=True)),
+    for kw in (dict(generator=dict(per_channel_noise=True)), dict(generator=dict(conv_only=True)),
                dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
@@ -311,7 +315,13 @@ def test_against_reference_fixture(dev, name):
         assert rel(g({"z": z})[0]["x"], c["fake"]) < 1e-4
         assert rel(d({"x": real})[0], c["score"]) < 1e-4
 
+    # (state that moves with every forward -- the vectors of a spectral norm -- starts every evaluation from here)
+    moving = [(b, b.clone()) for net in (g, d) for b in net.buffers()]
+
     def evaluate(jitter=lambda t: t):
+        with torch.no_grad():
+            for b, saved in moving:
+                b.copy_(saved)
         np.random.seed(seed + 1)
         d_loss = losses.discriminator_loss(d, g, {"x": jitter(real)}, {"z": jitter(z)}, loss_type, 1e-3, 10.0, 1.0,
                                            mixing=mix)
@@ -435,5 +445,59 @@ def test_graph_trainer_with_other_to_rgb(dev, mode):
         base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
         graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
         E._same_trajectory(base, graphed, f"graph replay, to_rgb {mode}", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(256, 257, 3), (64, 5, 1), (1, 256, 1), (256, 256, 32), (64, 1, 3), (5, 64, 3)])
+def test_spectral_norm_against_torch(dev, shape):
+    """The spectral normalisation of a weight (one power iteration in place, sigma, the normalised weight and its
+    gradient with the vectors as constants) against float64 torch, 2e-5; evaluation mode leaves the vectors alone."""
+    import torch.nn.functional as F
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(shape, generator=gen)
+    rows, cols = shape[0], shape[1] * shape[2]
+    u = F.normalize(torch.randn(rows, generator=gen), dim=0)
+    v = F.normalize(torch.randn(cols, generator=gen), dim=0)
+    g = torch.randn(shape, generator=gen)
+    w64 = w.double().requires_grad_(True)
+    wm = w64.reshape(rows, cols)
+    with torch.no_grad():
+        v1 = F.normalize(wm.t() @ u.double(), dim=0, eps=1e-12)
+        u1 = F.normalize(wm @ v1, dim=0, eps=1e-12)
+    sigma = torch.dot(u1, wm @ v1)
+    ref = w64 / sigma
+    (gref,) = torch.autograd.grad(ref, w64, g.double())
+    wd, ud, vd = w.to(dev).requires_grad_(True), u.to(dev), v.to(dev)
+    w_sn, sg = ops.spectral_norm(wd, ud, vd, 1e-12, True)
+    assert rel(w_sn, ref) < 2e-5 and rel(sg, sigma.reshape(1)) < 2e-5
+    assert rel(ud, u1) < 2e-5 and rel(vd, v1) < 2e-5
+    (gw,) = torch.autograd.grad(w_sn, wd, g.to(dev))
+    assert rel(gw, gref) < 2e-5
+    # evaluation mode: sigma from the stored vectors
+    u2, v2 = ud.clone(), vd.clone()
+    w_ev, sg_ev = ops.spectral_norm(wd, ud, vd, 1e-12, False)
+    assert torch.equal(ud, u2) and torch.equal(vd, v2)
+    assert rel(sg_ev, torch.dot(u1, wm.detach() @ v1).reshape(1)) < 2e-5 and rel(w_ev, ref) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["discriminator", "generator"])
+def test_graph_trainer_with_spectral_norm(dev, where):
+    """Spectral norm under the graph trainer: the power-iteration vectors move inside the captured graphs exactly as
+    in the eager trainer (the critic iteration stays one chain -- two passes side by side would race on the vectors
+    -- and a spectral generator makes its fakes per critic iteration)."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models={"shared": dict(equalized=False), where: dict(spectral=True)})
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        E._same_trajectory(base, graphed, f"graph replay, spectral {where}", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")

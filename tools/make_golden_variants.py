@@ -5,7 +5,7 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
 separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
-modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, and the generator loss's random multiplier
+modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, and the generator loss's random multiplier
 and feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
@@ -51,6 +51,13 @@ CASES = {
     "to_rgb_sagan": dict(generator=dict(to_rgb_mode="sagan"), depth=3, alpha=1.0),
     "to_rgb_biggan": dict(generator=dict(to_rgb_mode="biggan"), depth=2, alpha=0.7),
     "to_rgb_biggan_plain": dict(generator=dict(to_rgb_mode="biggan", no_tanh=True), depth=1, alpha=1.0),
+    # spectral norm of every conv weight: one power iteration per forward, so the runs below start from the
+    # vectors drawn at construction and make their passes in the same order
+    # (not equalized: a normalised weight times the equalized layers' input scale leaves no signal to compare)
+    "spectral_d": dict(shared=dict(equalized=False), discriminator=dict(spectral=True), depth=2, alpha=0.6),
+    "spectral_g": dict(shared=dict(equalized=False), generator=dict(spectral=True), depth=2, alpha=1.0),
+    "spectral_both": dict(shared=dict(equalized=False, self_attention_layers=[1]), generator=dict(spectral=True),
+                          discriminator=dict(spectral=True), depth=3, alpha=1.0, gamma=0.3),
 }
 
 
@@ -59,6 +66,7 @@ def oracle_config(case):
     sh, ge, di = case.get("shared", {}), case.get("generator", {}), case.get("discriminator", {})
     if "residual" in sh:
         kw["residual"] = sh["residual"]
+    # ("equalized" and "spectral" need no oracle option: the scales and the state dict carry them)
     if "act_alpha" in sh:
         kw["act_alpha"] = sh["act_alpha"]
     if "deep" in sh:
@@ -132,6 +140,8 @@ def main():
         def run_ref(dtype):
             g, d = build_pair(case)
             g, d = g.to(dtype), d.to(dtype)
+            # (the state the passes below start from: the vectors of a spectral norm move at every forward)
+            start = tuple({k: v.detach().clone() for k, v in m.state_dict().items()} for m in (g, d))
             g.depth = d.depth = depth
             g.alpha = d.alpha = alpha
             ga, da = M.GAdapter(g), M.DAdapter(d)
@@ -156,14 +166,14 @@ def main():
             g_loss.backward()
             g_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
             ref_losses.one = ref_losses.zero = None
-            return g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads
+            return g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads, start
 
         r32 = run_ref(torch.float32)
-        g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads = run_ref(torch.float64)
-        # the CPU restatement on the same draws
+        g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads, start = run_ref(torch.float64)
+        # the CPU restatement on the same draws, from the same starting state
         cfg = oracle_config(case)
-        gp, gs = M.to_oracle(g, torch.float64)
-        dp, ds = M.to_oracle(d, torch.float64)
+        gp, gs = {k: v.clone() for k, v in start[0].items()}, M.scales_of(g)
+        dp, ds = {k: v.clone() for k, v in start[1].items()}, M.scales_of(d)
         for p in list(gp.values()) + list(dp.values()):
             p.requires_grad_(True)
         np.random.seed(seed)
