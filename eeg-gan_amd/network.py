@@ -11,8 +11,9 @@ the critic's ``input_to_all_layers``
 (network.py:533-549) and ``self_attention_layers`` (layers.py:41-64; network.py:304-310, 324-330, 503-509, 550-553), and in the
 generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 190-213; network.py:299, 317-322)
 and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
-``to_rgb_mode`` (network.py:173-187), and ``spectral`` in either network (spectral norm of every conv weight,
-layers.py:170-171).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+``to_rgb_mode`` (network.py:173-187), ``spectral`` in either network (spectral norm of every conv weight,
+layers.py:170-171) and ``conv_only`` (fully convolutional networks: k-tap layers in place of the full-length ones, the
+critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -112,7 +113,8 @@ class Generator(nn.Module):
                  act_norm="pixel", conv_only=False, shared_embedding_size=32, normalize_latents=True,
                  rgb_generation_mode="pggan"):
         super().__init__()
-        _require(num_classes == 0 and not conv_only, "conditioning/conv_only")
+        _require(num_classes == 0, "conditioning")
+        _require(not conv_only or not (z_to_bn or split_z), "conv_only with z_to_bn / split_z")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         _require(not per_channel_noise, "per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
@@ -128,7 +130,9 @@ class Generator(nn.Module):
         self.alpha_dev = None
         self.split_z = bool(split_z) and not deep  # (network.py:270-272)
         self.z_distribution = z_distribution
-        self.conv_only = False
+        # (network.py:33-36, 274, 303, 364-365: a fully convolutional generator takes latents [B, latent, L] and starts
+        # with an ordinary k-tap layer instead of the full-length one)
+        self.conv_only = bool(conv_only)
         self.initial_kernel_size = initial_kernel_size
         self.normalize_latents = normalize_latents
         self.z_to_bn = bool(z_to_bn)
@@ -148,8 +152,8 @@ class Generator(nn.Module):
         layer_settings = dict(z_to_bn_size=latent_size if z_to_bn else 0, equalized=equalized, spectral=spectral,
                               init=init, act_alpha=act_alpha, do=dropout, num_classes=num_classes, act_norm=act_norm,
                               bias=True, separable=separable)
-        self.block0 = GBlock(latent_size, nf(1), initial_kernel_size=initial_kernel_size, **block_settings,
-                             **layer_settings)
+        self.block0 = GBlock(latent_size, nf(1), initial_kernel_size=None if conv_only else initial_kernel_size,
+                             **block_settings, **layer_settings)
         self.self_attention = dict()  # (network.py:304-310: stage -> layer; registered through ``dummy``)
         attention = [SelfAttention(nf(layer + 1), spectral, init) for layer in self_attention_layers or ()]
         self.self_attention.update(zip(self_attention_layers or (), attention))
@@ -188,6 +192,8 @@ class Generator(nn.Module):
         _require(y is None, "conditional generation")
         if self.normalize_latents:
             z = pixel_norm(z)
+        if self.conv_only and z.dim() != 3:
+            raise ValueError("a conv_only generator takes latents [B, latent, L]")
         h = z.unsqueeze(2) if z.dim() == 2 else z
         if self.split_z:
             # network.py:317-322, 368-371: the first share feeds the first layer, share 2 + l the batch norms of
@@ -227,9 +233,10 @@ class DBlock(nn.Module):
                  deep=False, group_size=4, temporal_groups_per_window=1, conv_disc=False, sinc=False,
                  **layer_settings):
         super().__init__()
-        _require(not conv_disc and not sinc, "DBlock(conv_disc/sinc)")
+        _require(not sinc, "DBlock(sinc)")
         last = initial_kernel_size is not None
         stats = last and group_size >= 0
+        full_length = last and not conv_disc  # (network.py:416-418: a fully convolutional critic keeps k-tap layers)
         hidden = max((ch_out // 4) if deep else ch_in, 4)  # (network.py:407-418)
         net = []
         if stats:
@@ -238,16 +245,16 @@ class DBlock(nn.Module):
         if deep:
             net.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
             net.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
-        net.append(GeneralConv(hidden, ch_out, kernel_size=initial_kernel_size if last else k_size,
-                               pad=0 if last else None, **layer_settings))
+        net.append(GeneralConv(hidden, ch_out, kernel_size=initial_kernel_size if full_length else k_size,
+                               pad=0 if full_length else None, **layer_settings))
         self.net = nn.Sequential(*net)
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
         self.from_rgb = GeneralConv(ch_rgb, ch_in, kernel_size=1, act_alpha=layer_settings["act_alpha"],
                                     **rgb_settings)
         self.residual = None
-        if not last and deep:  # (network.py:431-438: the block with the full-length layer has no skip)
+        if not full_length and deep:  # (network.py:431-438: the block with the full-length layer has no skip)
             self.residual = ConcatResidual(ch_in, ch_out, **rgb_settings)
-        elif not last and is_residual:
+        elif not full_length and is_residual:
             self.residual = nn.Identity() if ch_in == ch_out else GeneralConv(ch_in, ch_out, kernel_size=1,
                                                                               act_alpha=-1, **rgb_settings)
         self.deep = deep
@@ -270,7 +277,7 @@ class Discriminator(nn.Module):
                  temporal_groups_per_window=1, conv_only=False, input_to_all_layers=False, initial_sampling_rate=1.0,
                  sinc=False):
         super().__init__()
-        _require(num_classes == 0 and not conv_only and not sinc, "conditioning/conv_only/sinc")
+        _require(num_classes == 0 and not sinc, "conditioning/sinc")
         _require(act_norm is None, "an activation norm in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
@@ -342,6 +349,7 @@ class Discriminator(nn.Module):
             if (i - 2) in self.self_attention:  # (network.py:550-553)
                 h, maps[i] = self.self_attention[i - 2](h)
         o = self.linear(h)
-        if o.shape[2] != 1:
-            o = resample_signal(o, o.shape[2], 1)  # mean over time as an average pool
+        if o.shape[2] != 1:  # (network.py:554) the mean over time, as a product with a constant vector
+            ones = o.new_ones((o.shape[0], o.shape[2], 1))
+            o = ops.bmm(o, ones, alpha=1.0 / o.shape[2])
         return o.reshape(o.shape[0]), h, maps

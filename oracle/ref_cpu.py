@@ -64,6 +64,8 @@ class NetConfig:
     z_to_bn: bool = False                  # batch norms modulated by the latent (network.py:253, 299, 317-322)
     split_z: bool = False                  # one share of the latent per block (network.py:294-295, 317-322, 368-371)
     to_rgb_mode: str = "pggan"             # 'sngan' | 'sagan' | 'biggan' (network.py:173-187)
+    g_conv_only: bool = False              # latents [B, latent, L], k-tap first layer (network.py:33-36, 303, 364-365)
+    d_conv_only: bool = False              # k-tap last layer, score = mean over time (network.py:416-418, 554)
 
     def nf(self, stage: int) -> int:
         """network.py:279-280."""
@@ -359,6 +361,7 @@ def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", f
     ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
     ls = dict(act_alpha=cfg.act_alpha, norm=cfg.g_act_norm, drop=cfg.g_dropout, src=src, z=z)
     x = h
+    first = first and not cfg.g_conv_only  # (network.py:35, 303: a fully convolutional generator has no full-length layer)
     h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
     h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
     if cfg.deep:  # network.py:167-169, 213-216; PassChannelResidual (layers.py:216-223): the input's first channels
@@ -409,14 +412,26 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
     if first:
         h = general_conv(h, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
     if pos == cfg.num_stages:
-        if cfg.group_size < 0:  # no MinibatchStddev module in the block (network.py:405-406): the convs are net.0, net.1
-            h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
-            return general_conv(h, params, scales, f"blocks.{pos}.net.1", pad=0, **ls)
-        h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
-        n = 4 if cfg.deep else 2  # (deep: two more layers in the middle, network.py:411-415)
-        for i in range(1, n):
+        x = h
+        base = 0  # (without MinibatchStddev, network.py:405-406, the convs are net.0, net.1, ...)
+        if cfg.group_size >= 0:
+            h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
+            base = 1
+        n = base + (3 if cfg.deep else 1)  # (deep: two more layers in the middle, network.py:411-415)
+        for i in range(base, n):
             h = general_conv(h, params, scales, f"blocks.{pos}.net.{i}", **ls)
-        return general_conv(h, params, scales, f"blocks.{pos}.net.{n}", pad=0, **ls)
+        if not cfg.d_conv_only:
+            return general_conv(h, params, scales, f"blocks.{pos}.net.{n}", pad=0, **ls)
+        # fully convolutional critic (network.py:416-418, 431-438): a k-tap layer, and the block keeps its skip
+        h = general_conv(h, params, scales, f"blocks.{pos}.net.{n}", **ls)
+        if cfg.deep:
+            skip = f"blocks.{pos}.residual.net"
+            if has_layer(params, f"{skip}.conv.conv"):
+                return h + torch.cat([x, general_conv(x, params, scales, skip, act_alpha=-1)], dim=1)
+            return h + x
+        if cfg.residual:
+            h = h + _skip(params, scales, f"blocks.{pos}.residual", x)
+        return h
     x = h
     h = general_conv(h, params, scales, f"blocks.{pos}.net.0", **ls)
     h = general_conv(h, params, scales, f"blocks.{pos}.net.1", **ls)
@@ -450,7 +465,9 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
             return self_attention(params, scales, f"dummy.{list(cfg.self_attention_layers).index(layer)}", h)[0]
         return h
 
-    h = (pixel_norm(z) if cfg.normalize_latents else z).unsqueeze(2)
+    h = pixel_norm(z) if cfg.normalize_latents else z
+    if h.dim() == 2:  # (network.py:364-367: a fully convolutional generator is given [B, latent, L])
+        h = h.unsqueeze(2)
     whole = h
     if cfg.split_z:  # network.py:294-295, 368-371: the first share is the first layer's input
         share = cfg.latent_size // (cfg.num_stages + 2)

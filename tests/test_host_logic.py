@@ -40,13 +40,13 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
     with pytest.raises(NotImplementedError):
-        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True})
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True, "split_z": True})
     with pytest.raises(NotImplementedError):
         Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):
         Discriminator(**{**kw, "num_classes": 10}, **config.DISCRIMINATOR_KWARGS)
     with pytest.raises(NotImplementedError):
-        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "conv_only": True})
+        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "sinc": True})
 
 
 def test_depth_manager_schedule():

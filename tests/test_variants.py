@@ -2,7 +2,7 @@
 generator's 'residual' / 'mean' signal modes (332-349), the critic's input at every stage (533-549), plain layers
 (ReLU, no equalization, xavier init, to_rgb without tanh, latents not normalised, no MinibatchStddev), separable
 layers, deep blocks, self attention (layers.py:41-64), batch norm in the generator plain and modulated by the latent
-(layers.py:93-134), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb (network.py:173-187), spectral norm (layers.py:170-171) and the generator loss's
+(layers.py:93-134), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb (network.py:173-187), spectral norm (layers.py:170-171), fully convolutional networks (network.py:364-365, 416-418) and the generator loss's
 random multiplier and feature-matching term (losses.py:46, 62-70).
 
 Fixture ``variants.npz`` (``tools/make_golden_variants.py``): per case one critic and one generator loss evaluation
@@ -43,6 +43,8 @@ CASES = {
     "spectral_g": dict(shared=dict(equalized=False), generator=dict(spectral=True)),
     "spectral_both": dict(shared=dict(equalized=False, self_attention_layers=[1]), generator=dict(spectral=True),
                           discriminator=dict(spectral=True), gamma=0.3),
+    "conv_only_d": dict(shared=dict(residual=True), discriminator=dict(conv_only=True)),
+    "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True)),
 }
 
 
@@ -72,6 +74,8 @@ def _oracle_config(case):
         kw.update({k: src[k] for k in keys if k in src})
     if "act_norm" in case.get("generator", {}):
         kw["g_act_norm"] = case["generator"]["act_norm"]
+    kw["g_conv_only"] = bool(case.get("generator", {}).get("conv_only"))
+    kw["d_conv_only"] = bool(case.get("discriminator", {}).get("conv_only"))
     return O.NetConfig(**kw)
 
 
@@ -126,7 +130,7 @@ def test_oracle_matches_reference(name):
 
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
-    for kw in (dict(generator=dict(per_channel_noise=True)), dict(generator=dict(conv_only=True)),
+    for kw in (dict(generator=dict(per_channel_noise=True)), dict(discriminator=dict(sinc=True)),
                dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
@@ -499,5 +503,23 @@ def test_graph_trainer_with_spectral_norm(dev, where):
         base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
         graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
         E._same_trajectory(base, graphed, f"graph replay, spectral {where}", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+def test_graph_trainer_with_conv_only_critic(dev):
+    """A fully convolutional critic (k-tap last layer with its skip, score = mean over time) under the graph trainer:
+    the trajectory is the eager trainer's."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models=dict(shared=dict(residual=True), discriminator=dict(conv_only=True)))
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        E._same_trajectory(base, graphed, "graph replay, conv_only critic", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")

@@ -5,7 +5,7 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
 separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
-modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, and the generator loss's random multiplier
+modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, fully convolutional networks, and the generator loss's random multiplier
 and feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
@@ -58,6 +58,9 @@ CASES = {
     "spectral_g": dict(shared=dict(equalized=False), generator=dict(spectral=True), depth=2, alpha=1.0),
     "spectral_both": dict(shared=dict(equalized=False, self_attention_layers=[1]), generator=dict(spectral=True),
                           discriminator=dict(spectral=True), depth=3, alpha=1.0, gamma=0.3),
+    # fully convolutional networks: the critic alone (its score the mean over time), and both (latents [B, 256, 32])
+    "conv_only_d": dict(shared=dict(residual=True), discriminator=dict(conv_only=True), depth=2, alpha=0.6),
+    "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True), depth=2, alpha=1.0, z_len=32),
 }
 
 
@@ -78,6 +81,7 @@ def oracle_config(case):
             kw[k] = ge[k]
     if "act_norm" in ge:
         kw["g_act_norm"] = ge["act_norm"]
+    kw["g_conv_only"], kw["d_conv_only"] = bool(ge.get("conv_only")), bool(di.get("conv_only"))
     for k in ("input_to_all_layers", "group_size"):
         if k in di:
             kw[k] = di[k]
@@ -134,7 +138,7 @@ def main():
         rng = np.random.default_rng(seed)
         real32 = torch.from_numpy(O.synthetic_eeg(batch, cfgmod.NUM_CHANNELS, T, rng))
         torch.manual_seed(seed)
-        z32 = torch.randn(batch, cfgmod.LATENT_SIZE)
+        z32 = torch.randn(batch, cfgmod.LATENT_SIZE, *([case["z_len"]] if "z_len" in case else []))
         mix32 = torch.rand(batch, 1, 1)
 
         def run_ref(dtype):
