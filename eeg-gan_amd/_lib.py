@@ -72,6 +72,9 @@ SIGNATURES = {
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_feature_match_fwd": (_i, [_f, _f, _f, _f, _i, _i, _st]),
     "eeggan_feature_match_bwd": (_i, [_f, _f, _f, _i, _i, _st]),
+    "eeggan_channel_sum": (_i, [_f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_channel_affine": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
+    "eeggan_product": (_i, [_f, _f, _f, _sz, _st]),
     "eeggan_spectral_norm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _i, _st]),
     "eeggan_spectral_norm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _st]),
     "eeggan_bn_lrelu_drop_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _fl, _fl, _fl, _i, _st]),

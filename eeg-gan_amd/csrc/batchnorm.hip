@@ -151,10 +151,66 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     gc[i] = train ? k * (g_o - s1[ch] * inv_n - nn * s2[ch] * inv_n) : k * g_o;
 }
 
+// ---- pieces of a batch norm that is differentiated twice (the critic's, under the gradient penalty): sums over
+// (batch, time) per channel, a per-channel scale and shift, and a plain product.  Each is linear in each argument, so
+// the backward of every one of them is made of the same three.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                                                          int T, float scale) {
+    __shared__ double red[256];
+    const int ch = blockIdx.x;
+    const long long per = (long long)B * T;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < per; i += 256) {
+        const int b = (int)(i / T), t = (int)(i - (long long)b * T);
+        s += (double)x[((long long)b * C + ch) * T + t];
+    }
+    const double tot = block_sum_256d(s, red);
+    if (threadIdx.x == 0) out[ch] = (float)(tot * (double)scale);
+}
+
+// y = x * s[ch] + t[ch]   (x NULL: y = t[ch]; s NULL: 1; t NULL: 0)
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             const float* __restrict__ t, float* __restrict__ y, int C, int T,
+                                                             long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ch = (int)((i / T) % C);
+    const float v = x ? x[i] * (s ? s[ch] : 1.f) : 0.f;
+    y[i] = v + (t ? t[ch] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void product_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
 }  // namespace
 }  // namespace eeggan
 
 using namespace eeggan;
+
+extern "C" int eeggan_channel_sum(const float* x, float* out, int B, int C, int T, float scale, void* stream) {
+    EEGGAN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "channel_sum: bad arguments");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), x, out, B, C, T, scale);
+    return check_launch("channel_sum");
+}
+
+extern "C" int eeggan_channel_affine(const float* x, const float* s, const float* t, float* y, int B, int C, int T,
+                                     void* stream) {
+    EEGGAN_REQUIRE(y && (x || t) && B > 0 && C > 0 && T > 0, "channel_affine: bad arguments");
+    const long long n = (long long)B * C * T;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, s, t, y, C, T,
+                       n);
+    return check_launch("channel_affine");
+}
+
+extern "C" int eeggan_product(const float* a, const float* b, float* out, size_t count, void* stream) {
+    EEGGAN_REQUIRE(a && b && out && count > 0, "product: bad arguments");
+    hipLaunchKernelGGL(product_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, out,
+                       (long long)count);
+    return check_launch("product");
+}
 
 extern "C" int eeggan_bn_lrelu_drop_fwd(const float* c, const float* gamma, const float* beta, const float* gmod,
                                         const float* bmod, const float* drop, float* run_mean, float* run_var, float* mean,

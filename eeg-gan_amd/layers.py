@@ -233,6 +233,10 @@ class ConditionalBatchNorm(nn.Module):
         beta = ops.channel_window(e, None, n, 0, n, channels=n, length=1).reshape(e.shape[0], n)
         return gamma, beta
 
+    # the critic's norms are differentiated twice (gradient penalty): the Discriminator sets this, and the layer then
+    # runs as a chain of multilinear pieces instead of the fused first-order kernel pair
+    second_order = False
+
     def apply_with(self, c, z, drop, slope):
         """drop * lrelu_slope(this norm of c): the epilogue GeneralConv asks for (slope 1 and no drop: the norm alone)."""
         bn = self.normalizer
@@ -241,6 +245,11 @@ class ConditionalBatchNorm(nn.Module):
         gmod, bmod = self.modulation(z)
         if train and bn.track_running_stats:
             bn.num_batches_tracked += 1
+        if self.second_order:
+            if self.mode != "BN":
+                raise NotImplementedError("a latent-modulated batch norm that is differentiated twice")
+            o = ops.batch_norm_twice(c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, train)
+            return o if (drop is None and slope == 1.0) else ops.lrelu_drop(o, drop, slope)
         return ops.bn_act(c, drop, bn.weight, bn.bias, gmod, bmod, bn.running_mean, bn.running_var, slope, bn.eps,
                           momentum, train)
 
@@ -449,10 +458,18 @@ class GeneralConv(nn.Module):
             return ops.g_layer(x, w, b, None, s, 0.0, mode="tanh", kind="same", tanh_scale=_tanh_scale, flip=c._flip)
         if self.act_norm == "batch":
             # conv without bias -> batch norm (-> modulation by the latent) -> (leaky) ReLU -> GDrop (layers.py:207-213)
-            if kind == "tail":
-                raise NotImplementedError("batch norm after the critic's full-length layer")
-            xin = x.squeeze(2) if kind == "head" else x
-            c_lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
+            if self.norm.second_order:  # the critic: every piece twice differentiable
+                if kind == "same":
+                    c_lin = ops.conv1d(x, w, b, None, s, ACT_NONE, flip=c._flip)
+                elif kind == "tail":  # (the full-length layer with slope 1: linear)
+                    c_lin = ops.tail_conv(x, w, b, None, s, 1.0)
+                else:
+                    raise NotImplementedError("batch norm after a length-1 (head) conv in the critic")
+            else:
+                if kind == "tail":
+                    raise NotImplementedError("batch norm after the full-length layer outside the critic")
+                xin = x.squeeze(2) if kind == "head" else x
+                c_lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
             return self.norm.apply_with(c_lin, z, self._multipliers(x), slope if self.act_alpha >= 0 else 1.0)
         if self.act_norm == "pixel":
             if self.act_alpha < 0 or kind == "tail":

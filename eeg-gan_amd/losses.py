@@ -82,6 +82,12 @@ def _frozen(module: torch.nn.Module):
 LOSS_TYPES = ("hinge", "rsgan", "rasgan", "rahinge", "wgan_gp", "wgan_theirs")
 
 
+def _batch_coupled(dis) -> bool:
+    """Batch statistics couple the samples of a pass: such a critic is given reals, fakes and interpolates one after
+    the other, as the reference does (losses.py:76-79, 107-111), never stacked."""
+    return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in dis.modules())
+
+
 class PartsUnavailable(ValueError):
     """The critic loss was asked for one of its independent parts but does not split for this configuration."""
 
@@ -148,8 +154,11 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         dis.zero_grad()
     real_x = real["x"] if isinstance(real, dict) else real
     if stack_real_fake is None:
-        stack_real_fake = layers.get_drop_mode() == "device"
+        stack_real_fake = layers.get_drop_mode() == "device" and not _batch_coupled(dis)
     if part is not None and not stack_real_fake:
+        if _batch_coupled(dis):
+            raise PartsUnavailable("a critic with batch norm layers sees reals, fakes and interpolates as batches of "
+                                   "their own")
         raise ValueError("part needs the stacked critic pass")
     if stack_real_fake:
         # one critic pass over [reals; fakes]: half the launches, twice the work per launch, and one
@@ -217,8 +226,11 @@ def _other_discriminator_loss(dis, gen, real, z, loss_type, drift, grad_lambda, 
     real_x = real["x"] if isinstance(real, dict) else real
     n = real_x.size(0)
     if stack_real_fake is None:
-        stack_real_fake = layers.get_drop_mode() == "device"
+        stack_real_fake = layers.get_drop_mode() == "device" and not _batch_coupled(dis)
     if part is not None and not stack_real_fake:
+        if _batch_coupled(dis):
+            raise PartsUnavailable("a critic with batch norm layers sees reals, fakes and interpolates as batches of "
+                                   "their own")
         raise ValueError("part needs the stacked critic pass")
     d_real = d_fake = None
     if stack_real_fake:

@@ -13,7 +13,8 @@ generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 19
 and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
 ``to_rgb_mode`` (network.py:173-187), ``spectral`` in either network (spectral norm of every conv weight,
 layers.py:170-171) and ``conv_only`` (fully convolutional networks: k-tap layers in place of the full-length ones, the
-critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554), and ``act_norm='batch'`` in the critic
+(differentiated twice under the gradient penalty).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -22,7 +23,7 @@ import numpy as np
 from torch import nn
 
 from . import ops
-from .layers import ConcatResidual, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh, SelfAttention
+from .layers import ConcatResidual, ConditionalBatchNorm, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh, SelfAttention
 from .utils import pixel_norm, resample_signal
 
 
@@ -278,7 +279,7 @@ class Discriminator(nn.Module):
                  sinc=False):
         super().__init__()
         _require(num_classes == 0 and not sinc, "conditioning/sinc")
-        _require(act_norm is None, "an activation norm in the discriminator")
+        _require(act_norm in (None, "batch"), "an activation norm other than 'batch' in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
         self.progression_scale_up = progression_scale_up
@@ -315,6 +316,9 @@ class Discriminator(nn.Module):
         self.linear = GeneralConv(nf(0), 1, kernel_size=1, equalized=equalized, act_alpha=-1, spectral=spectral,
                                   init=init)
         self.max_depth = len(self.blocks) - 1
+        for m in self.modules():  # (batch norms under the gradient penalty are differentiated twice)
+            if isinstance(m, ConditionalBatchNorm):
+                m.second_order = True
 
     def _shrink(self, h, stage):
         return resample_signal(h, self.progression_scale_up[stage], self.progression_scale_down[stage])

@@ -1026,6 +1026,105 @@ def bn_act(c, drop, gamma, beta, gmod, bmod, run_mean, run_var, slope, eps, mome
                         bool(train))
 
 
+# ---- a batch norm that can be differentiated twice (the critic's): three multilinear pieces whose backwards are
+# made of each other, so autograd derives every order from them
+class _ChanSum(Function):
+    """[B, C, T] -> [C]: scale * the sum over (batch, time)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _chk(x, "channel sum input")
+        B, C, T = x.shape
+        out = torch.empty((C,), device=x.device, dtype=torch.float32)
+        call("eeggan_channel_sum", x.data_ptr(), out.data_ptr(), B, C, T, float(scale), _stream())
+        ctx.cfg = (B, T, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, scale = ctx.cfg
+        return _ChanAffine.apply(None, None, g * scale, (B, g.shape[0], T)), None
+
+
+class _ChanAffine(Function):
+    """x * s[ch] + t[ch] over [B, C, T] (x None: t[ch] spread over ``shape``; s / t None: 1 / 0)."""
+
+    @staticmethod
+    def forward(ctx, x, s, t, shape):
+        B, C, T = shape
+        ref = x if x is not None else t
+        for v, what in ((s, "scale"), (t, "shift")):
+            if v is not None and not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == C):
+                raise RuntimeError(f"channel affine: {what} must be a contiguous float32 device vector of {C} elements")
+        if x is not None:
+            x = _chk(x, "channel affine input")
+        y = torch.empty((B, C, T), device=ref.device, dtype=torch.float32)
+        call("eeggan_channel_affine", _p(x), _p(s), _p(t), y.data_ptr(), B, C, T, _stream())
+        ctx.save_for_backward(x, s)
+        ctx.shape = shape
+        ctx.has = (x is not None, s is not None, t is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        has_x, has_s, has_t = ctx.has
+        g = g.contiguous()
+        gx = gs = gt = None
+        if has_x and ctx.needs_input_grad[0]:
+            gx = _ChanAffine.apply(g, s, None, ctx.shape) if has_s else g
+        if has_s and ctx.needs_input_grad[1]:
+            gs = _ChanSum.apply(_Product.apply(g, x), 1.0)
+        if has_t and ctx.needs_input_grad[2]:
+            gt = _ChanSum.apply(g, 1.0)
+        return gx, gs, gt, None
+
+
+class _Product(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "product a"), _chk(b, "product b")
+        if a.shape != b.shape:
+            raise RuntimeError("product: shapes differ")
+        out = torch.empty_like(a)
+        call("eeggan_product", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        return (_Product.apply(g, b) if ctx.needs_input_grad[0] else None,
+                _Product.apply(g, a) if ctx.needs_input_grad[1] else None)
+
+
+def batch_norm_twice(c, gamma, beta, run_mean, run_var, eps, momentum, train):
+    """gamma * normalise(c) + beta with statistics over (batch, time) per channel (biased variance; evaluation mode:
+    the running ones), differentiable to any order.  The per-channel vectors in between are handled with torch's
+    own (tiny) operations.  Running statistics are updated like nn.BatchNorm1d's."""
+    B, C, T = c.shape
+    n = B * T
+    if train:
+        mean = _ChanSum.apply(c, 1.0 / n)
+        d = _ChanAffine.apply(c, None, -mean, (B, C, T))
+        var = _ChanSum.apply(_Product.apply(d, d), 1.0 / n)
+        if run_mean is not None:
+            with torch.no_grad():
+                run_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+                run_var.mul_(1.0 - momentum).add_(var, alpha=momentum * (n / (n - 1.0) if n > 1 else 1.0))
+        rstd = (var + eps).rsqrt()
+        return _ChanAffine.apply(d, (gamma * rstd).contiguous(), beta, (B, C, T))
+    rstd = (run_var + eps).rsqrt()
+    scale = (gamma * rstd).contiguous()
+    return _ChanAffine.apply(c, scale, (beta - run_mean * scale).contiguous(), (B, C, T))
+
+
+def lrelu_drop(o, drop, slope):
+    """drop[b, ch] * lrelu_slope(o), differentiable to any order (piecewise linear: the mask is a constant)."""
+    return _MaskMul.apply(o, o.detach(), drop, float(slope))
+
+
 class _SpectralNorm(Function):
     """w_orig / sigma with sigma = u^T W v of the weight as a matrix [output channels, rest], after one power iteration
     on the module's vectors ``u`` and ``v`` (in place) when ``iterate`` (torch.nn.utils.spectral_norm's arithmetic; the

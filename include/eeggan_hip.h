@@ -310,6 +310,16 @@ int eeggan_bn_lrelu_drop_bwd(const float* gy, const float* y, const float* c, co
                              float* g_gamma, float* g_beta, float* g_gmod, float* g_bmod, int B, int C, int T, float slope,
                              int train, void* stream);
 
+/* The pieces of a batch norm that is differentiated twice (the critic's layers under the gradient penalty, layers.py:93-134
+ * with act_norm = 'batch' in the Discriminator, network.py:496-497): each is linear in each argument, so every
+ * derivative of the norm is made of the same three. */
+/* out[ch] = scale * sum over (batch, time) of x[b, ch, t], in double, fixed order. */
+int eeggan_channel_sum(const float* x, float* out, int B, int C, int T, float scale, void* stream);
+/* y[b, ch, t] = x[b, ch, t] * s[ch] + t[ch]   (x NULL: y = t[ch]; s NULL: 1; t NULL: 0). */
+int eeggan_channel_affine(const float* x, const float* s, const float* t, float* y, int B, int C, int T, void* stream);
+/* out = a * b elementwise. */
+int eeggan_product(const float* a, const float* b, float* out, size_t count, void* stream);
+
 /* ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm as layers.py:170-171 and network.py:520-521
  * apply it): the weight as a matrix W [rows = output channels, cols = the other dimensions]. -------------------- */
 /* power_iteration != 0 (training): v <- normalize(W^T u), u <- normalize(W v) in place (normalize(x) = x / max(|x|, eps));

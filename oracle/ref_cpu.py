@@ -64,6 +64,7 @@ class NetConfig:
     z_to_bn: bool = False                  # batch norms modulated by the latent (network.py:253, 299, 317-322)
     split_z: bool = False                  # one share of the latent per block (network.py:294-295, 317-322, 368-371)
     to_rgb_mode: str = "pggan"             # 'sngan' | 'sagan' | 'biggan' (network.py:173-187)
+    d_act_norm: Optional[str] = None       # the critic layers' norm: None | 'batch' (network.py:455, 496-497)
     g_conv_only: bool = False              # latents [B, latent, L], k-tap first layer (network.py:33-36, 303, 364-365)
     d_conv_only: bool = False              # k-tap last layer, score = mean over time (network.py:416-418, 554)
 
@@ -408,7 +409,7 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
     """DBlock.forward, network.py:441-449 (no residual, not deep): optional from_rgb (1x1 conv + LeakyReLU,
     network.py:428-429), then two GeneralConvs with GDrop; the last block of the list prepends
     MinibatchStddev and ends in the full-length kernel without padding (network.py:403-418)."""
-    ls = dict(act_alpha=cfg.act_alpha, norm=None, drop=cfg.d_dropout, src=src)
+    ls = dict(act_alpha=cfg.act_alpha, norm=cfg.d_act_norm, drop=cfg.d_dropout, src=src)
     if first:
         h = general_conv(h, params, scales, f"blocks.{pos}.from_rgb", act_alpha=cfg.act_alpha)
     if pos == cfg.num_stages:

@@ -45,6 +45,7 @@ CASES = {
                           discriminator=dict(spectral=True), gamma=0.3),
     "conv_only_d": dict(shared=dict(residual=True), discriminator=dict(conv_only=True)),
     "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True)),
+    "d_batch_norm": dict(discriminator=dict(act_norm="batch")),
 }
 
 
@@ -76,6 +77,8 @@ def _oracle_config(case):
         kw["g_act_norm"] = case["generator"]["act_norm"]
     kw["g_conv_only"] = bool(case.get("generator", {}).get("conv_only"))
     kw["d_conv_only"] = bool(case.get("discriminator", {}).get("conv_only"))
+    if "act_norm" in case.get("discriminator", {}):
+        kw["d_act_norm"] = case["discriminator"]["act_norm"]
     return O.NetConfig(**kw)
 
 
@@ -131,7 +134,7 @@ def test_oracle_matches_reference(name):
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
     for kw in (dict(generator=dict(per_channel_noise=True)), dict(discriminator=dict(sinc=True)),
-               dict(discriminator=dict(act_norm="batch")), dict(shared=dict(num_classes=10))):
+               dict(discriminator=dict(act_norm="pixel")), dict(shared=dict(num_classes=10))):
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
@@ -521,5 +524,60 @@ def test_graph_trainer_with_conv_only_critic(dev):
         base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
         graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, **kw), E._two_steps(dev, GraphedTrainer, **kw)
         E._same_trajectory(base, graphed, "graph replay, conv_only critic", moment_tol=5e-5)
+    finally:
+        layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [True, False])
+def test_batch_norm_to_second_order(dev, train):
+    """The critic's batch norm (a chain of multilinear pieces) with its LeakyReLU and multipliers against float64
+    torch: values, first derivatives, and the derivatives of a penalty on the input gradient (the second order the
+    gradient penalty asks for); running statistics as nn.BatchNorm1d keeps them."""
+    import torch.nn.functional as F
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(5 + train)
+    B, C, T = 6, 20, 48
+    c = torch.randn(B, C, T, generator=gen) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    drop = torch.rand(B, C, generator=gen) + 0.5
+    rm, rv = torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5
+    q = torch.randn(B, C, T, generator=gen)
+
+    def run(dt, device, fn):
+        cc = c.to(device, dt).requires_grad_(True)
+        ga, be = gamma.to(device, dt).requires_grad_(True), beta.to(device, dt).requires_grad_(True)
+        m, v = rm.to(device, dt).clone(), rv.to(device, dt).clone()
+        y = fn(cc, ga, be, m, v, drop.to(device, dt))
+        (gc,) = torch.autograd.grad(y, cc, q.to(device, dt), create_graph=True)
+        pen = ((gc * gc).sum(dim=(1, 2)).sqrt() - 1.0).pow(2).sum() + (y * y).mean()
+        grads = torch.autograd.grad(pen, [cc, ga, be])
+        return [y, gc, *grads, m, v]
+
+    ref = run(torch.float64, "cpu", lambda cc, ga, be, m, v, dr: F.leaky_relu(
+        F.batch_norm(cc, m, v, ga, be, training=train, momentum=0.1, eps=1e-5), 0.2) * dr[:, :, None])
+    got = run(torch.float32, dev, lambda cc, ga, be, m, v, dr: ops.lrelu_drop(
+        ops.batch_norm_twice(cc, ga, be, m, v, 1e-5, 0.1, train), dr, 0.2))
+    for name, a, b in zip(("y", "input gradient", "d pen / d c", "d pen / d gamma", "d pen / d beta", "running mean",
+                           "running variance"), got, ref):
+        assert rel(a, b) < 5e-5, (name, rel(a, b))
+
+
+@pytest.mark.gpu
+def test_graph_trainer_with_batch_norm_critic(dev):
+    """Batch norm in the critic's layers under the graph trainer: reals, fakes and interpolates stay batches of their
+    own (one chain, no stacked pass), and the trajectory is the eager trainer's."""
+    import test_e2e_gpu as E
+    from eeggan_amd import layers
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.trainer import Trainer
+    layers.set_drop_mode("device")
+    try:
+        kw = dict(models=dict(discriminator=dict(act_norm="batch")))
+        seen = {}
+        base = E._two_steps(dev, Trainer, lr=0.0, **kw), E._two_steps(dev, Trainer, **kw)
+        graphed = E._two_steps(dev, GraphedTrainer, lr=0.0, seen=seen, **kw), E._two_steps(dev, GraphedTrainer, **kw)
+        assert seen["critic"] != "_SplitCriticIteration"
+        E._same_trajectory(base, graphed, "graph replay, batch norm critic", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")

@@ -5,7 +5,7 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
 separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
-modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, fully convolutional networks, and the generator loss's random multiplier
+modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, fully convolutional networks, batch norm in the critic, and the generator loss's random multiplier
 and feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
@@ -61,6 +61,8 @@ CASES = {
     # fully convolutional networks: the critic alone (its score the mean over time), and both (latents [B, 256, 32])
     "conv_only_d": dict(shared=dict(residual=True), discriminator=dict(conv_only=True), depth=2, alpha=0.6),
     "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True), depth=2, alpha=1.0, z_len=32),
+    # batch norm in the critic's layers: differentiated twice under the gradient penalty
+    "d_batch_norm": dict(discriminator=dict(act_norm="batch"), depth=2, alpha=0.6),
 }
 
 
@@ -82,6 +84,8 @@ def oracle_config(case):
     if "act_norm" in ge:
         kw["g_act_norm"] = ge["act_norm"]
     kw["g_conv_only"], kw["d_conv_only"] = bool(ge.get("conv_only")), bool(di.get("conv_only"))
+    if "act_norm" in di:
+        kw["d_act_norm"] = di["act_norm"]
     for k in ("input_to_all_layers", "group_size"):
         if k in di:
             kw[k] = di[k]
@@ -176,8 +180,8 @@ def main():
         g, d, real, z, mix, fake, score, d_loss, d_grads, g_loss, g_grads, start = run_ref(torch.float64)
         # the CPU restatement on the same draws, from the same starting state
         cfg = oracle_config(case)
-        gp, gs = {k: v.clone() for k, v in start[0].items()}, M.scales_of(g)
-        dp, ds = {k: v.clone() for k, v in start[1].items()}, M.scales_of(d)
+        gp, gs = {k: v.clone().to(torch.float64) for k, v in start[0].items()}, M.scales_of(g)
+        dp, ds = {k: v.clone().to(torch.float64) for k, v in start[1].items()}, M.scales_of(d)
         for p in list(gp.values()) + list(dp.values()):
             p.requires_grad_(True)
         np.random.seed(seed)
