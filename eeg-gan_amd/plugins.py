@@ -169,6 +169,42 @@ class OutputGenerator(Plugin):
             self.load_params(original, gen)
 
 
+class EvalDiscriminator(Plugin):
+    """The critic's mean score over the validation set, logged as ``memorization`` (reference plugins.py:205-232;
+    train.py:116-117 registers it when the critic's layers have a norm).  ``create_dataloader_fun(minibatch, is_training,
+    depth, alpha)`` yields batches as the reference's does."""
+
+    def __init__(self, create_dataloader_fun, output_snapshot_ticks):
+        super().__init__([(1, "epoch")])
+        self.create_dataloader_fun = create_dataloader_fun
+        self.output_snapshot_ticks = output_snapshot_ticks
+
+    def register(self, trainer):
+        self.trainer = trainer
+        self.trainer.stats["memorization"] = {
+            "log_name": "memorization",
+            "log_epoch_fields": ["{val:.2f}", "{epoch:.2f}"],
+            "val": float("nan"), "epoch": 0,
+        }
+
+    def epoch(self, epoch_index):
+        import numpy as np
+        import torch
+        from . import ops
+        from .utils import cudize
+        if epoch_index % self.output_snapshot_ticks != 0:
+            return
+        tr = self.trainer
+        values = []
+        with torch.no_grad():
+            for data in self.create_dataloader_fun(min(tr.stats["minibatch_size"], 1024), False, tr.dataset.model_depth,
+                                                   tr.dataset.alpha):
+                d_real, _, _ = tr.discriminator(cudize(data))
+                values.append(float(ops.mean_scale(d_real, 1.0)) if d_real.is_cuda else float(d_real.mean()))
+        tr.stats["memorization"]["val"] = np.array(values).mean()
+        tr.stats["memorization"]["epoch"] = epoch_index
+
+
 def __getattr__(name):
     # the metric plugins keep the reference's import path (plugins.SlicedWDistance, plugins.FidCalculator) but
     # live in metrics.py, which imports this module for the Plugin base class

@@ -222,3 +222,44 @@ def test_flip_cache_copy_follows_the_copied_parameter():
     assert twin._flip.param is twin.conv.weight and twin._flip.param is not conv.conv.weight
     assert twin._flip.tag is None and twin._flip.wt is None and twin._flip in ops.FlipCache._all
     assert twin._flip._stale()
+
+
+def test_eval_discriminator_plugin_logs_the_mean_score():
+    """EvalDiscriminator (reference plugins.py:205-232): on its ticks the mean of the critic's scores over the batches
+    the loader yields, under stats['memorization']; other ticks leave it alone."""
+    import torch
+    from eeggan_amd.plugins import EvalDiscriminator
+
+    class _D:
+        def __call__(self, data):
+            x = data["x"] if isinstance(data, dict) else data
+            return x.mean(dim=(1, 2)), None, {}
+
+    class _Set:
+        model_depth, alpha = 3, 0.5
+
+    class _Trainer:
+        stats = {"minibatch_size": 4000}
+        dataset = _Set()
+        discriminator = _D()
+
+    asked = []
+
+    def loader(minibatch, training, depth, alpha):
+        asked.append((minibatch, training, depth, alpha))
+        return [torch.full((2, 5, 8), 1.0), torch.full((2, 5, 8), 3.0)]
+
+    import eeggan_amd.utils as U
+    plug = EvalDiscriminator(loader, output_snapshot_ticks=2)
+    tr = _Trainer()
+    plug.register(tr)
+    assert tr.stats["memorization"]["log_name"] == "memorization"
+    saved, U.cudize = U.cudize, (lambda t: t)
+    try:
+        plug.epoch(1)
+        assert not asked and tr.stats["memorization"]["epoch"] == 0
+        plug.epoch(2)
+    finally:
+        U.cudize = saved
+    assert asked == [(1024, False, 3, 0.5)]
+    assert abs(tr.stats["memorization"]["val"] - 2.0) < 1e-6 and tr.stats["memorization"]["epoch"] == 2
