@@ -193,41 +193,61 @@ class MinibatchStddev(nn.Module):
 
 
 class ConditionalBatchNorm(nn.Module):
-    """Batch normalisation over (batch, time) per channel, optionally modulated per sample by the latent (reference
-    layers.py:93-134).  Modes: 'BN' (no conditioning: an affine ``nn.BatchNorm1d``'s arithmetic) and 'SM' (self
-    modulation: a normaliser without affine parameters, then ``out + gamma * out + beta`` with gamma / beta from a
-    two-layer 1x1 network on the latent).  The class-conditional modes ('CBN', 'CSM') are not built.  ``normalizer``
-    is the parameter and running-statistics container (same state-dict keys); training / evaluation follows
-    ``self.training``.  First-order differentiable: the layer belongs to the generator."""
+    """Batch normalisation over (batch, time) per channel, optionally modulated per sample (reference
+    layers.py:93-134).  Modes: 'BN' (no conditioning: an affine ``nn.BatchNorm1d``'s arithmetic); 'CBN' (a normaliser
+    without affine parameters, then ``out + gamma * out + beta`` with gamma / beta from a linear 1x1 layer on the
+    class embedding); 'SM' / 'CSM' (gamma / beta from a two-layer 1x1 network on the latent, or on the latent and the
+    class embedding stacked along the channels).  ``normalizer`` is the parameter and running-statistics container
+    (same state-dict keys); training / evaluation follows ``self.training``.  The conditioning inputs have one time
+    step (per-sample modulation).  First-order differentiable unless ``second_order`` is set."""
 
     def __init__(self, num_features, num_classes, latent_size, spectral):
         super().__init__()
-        if num_classes != 0:
-            raise NotImplementedError("ConditionalBatchNorm: the class-conditional modes ('CBN', 'CSM') are not supported")
-        no_cond = latent_size == 0
+        no_cond = latent_size == 0 and num_classes == 0
         self.num_features = num_features
         self.normalizer = nn.BatchNorm1d(num_features, affine=no_cond)
         if no_cond:
             self.mode = "BN"
+        elif latent_size == 0:
+            self.embed = GeneralConv(num_classes, num_features * 2, kernel_size=1, equalized=False, act_alpha=-1,
+                                     spectral=spectral, bias=False)
+            self.mode = "CBN"
         else:
             self.embed = nn.Sequential(
-                GeneralConv(latent_size, num_features * 2, kernel_size=1, equalized=False, act_alpha=0.0,
+                GeneralConv(latent_size + num_classes, num_features * 2, kernel_size=1, equalized=False, act_alpha=0.0,
                             spectral=spectral, bias=True),
                 GeneralConv(num_features * 2, num_features * 2, kernel_size=1, equalized=False, act_alpha=-1,
                             spectral=spectral, bias=False))
-            self.mode = "SM"
+            self.mode = "SM" if num_classes == 0 else "CSM"
 
-    def modulation(self, z):
-        """(gamma, beta), each [B, num_features], from the latent [B, latent] or [B, latent, 1]; (None, None) in
-        'BN' mode."""
+    @staticmethod
+    def _one_step(t, what):
+        t = t.unsqueeze(2) if t.dim() == 2 else t
+        if t.shape[2] != 1:
+            raise NotImplementedError(f"ConditionalBatchNorm: {what} with a time axis")
+        return t
+
+    def modulation(self, z, y=None):
+        """(gamma, beta), each [B, num_features], from the latent [B, latent(, 1)] and / or the class embedding
+        [B, classes(, 1)]; (None, None) in 'BN' mode."""
         if self.mode == "BN":
             return None, None
-        if z is None:
-            raise ValueError("ConditionalBatchNorm in 'SM' mode needs the latent")
-        z = z.unsqueeze(2) if z.dim() == 2 else z
-        if z.shape[2] != 1:
-            raise NotImplementedError("ConditionalBatchNorm: a latent with a time axis")
-        e = self.embed(z)  # [B, 2 F, 1]
+        if self.mode in ("CBN", "CSM"):
+            if y is None:
+                raise ValueError(f"ConditionalBatchNorm in '{self.mode}' mode needs the class embedding")
+            y = self._one_step(y, "a class embedding")
+        if self.mode in ("SM", "CSM"):
+            if z is None:
+                raise ValueError(f"ConditionalBatchNorm in '{self.mode}' mode needs the latent")
+            z = self._one_step(z, "a latent")
+        if self.mode == "CBN":
+            cond = y
+        elif self.mode == "SM":
+            cond = z
+        else:  # (layers.py:125-127) the latent's channels, then the embedding's
+            nz, ny = z.shape[1], y.shape[1]
+            cond = ops.channel_window(y, ops.channel_window(z, None, 0, 0, nz, channels=nz + ny, length=1), 0, nz, ny)
+        e = self.embed(cond)  # [B, 2 F, 1]
         n = self.num_features
         gamma = ops.channel_window(e, None, 0, 0, n, channels=n, length=1).reshape(e.shape[0], n)
         beta = ops.channel_window(e, None, n, 0, n, channels=n, length=1).reshape(e.shape[0], n)
@@ -237,12 +257,12 @@ class ConditionalBatchNorm(nn.Module):
     # runs as a chain of multilinear pieces instead of the fused first-order kernel pair
     second_order = False
 
-    def apply_with(self, c, z, drop, slope):
+    def apply_with(self, c, z, drop, slope, y=None):
         """drop * lrelu_slope(this norm of c): the epilogue GeneralConv asks for (slope 1 and no drop: the norm alone)."""
         bn = self.normalizer
         train = self.training or bn.running_mean is None
         momentum = 0.1 if bn.momentum is None else bn.momentum
-        gmod, bmod = self.modulation(z)
+        gmod, bmod = self.modulation(z, y)
         if train and bn.track_running_stats:
             bn.num_batches_tracked += 1
         if self.second_order:
@@ -254,7 +274,7 @@ class ConditionalBatchNorm(nn.Module):
                           momentum, train)
 
     def forward(self, x, y=None, z=None):
-        return self.apply_with(x, z, None, 1.0)
+        return self.apply_with(x, z, None, 1.0, y=y)
 
 
 
@@ -470,7 +490,7 @@ class GeneralConv(nn.Module):
                     raise NotImplementedError("batch norm after the full-length layer outside the critic")
                 xin = x.squeeze(2) if kind == "head" else x
                 c_lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
-            return self.norm.apply_with(c_lin, z, self._multipliers(x), slope if self.act_alpha >= 0 else 1.0)
+            return self.norm.apply_with(c_lin, z, self._multipliers(x), slope if self.act_alpha >= 0 else 1.0, y=y)
         if self.act_norm == "pixel":
             if self.act_alpha < 0 or kind == "tail":
                 raise NotImplementedError("pixel norm is fused with a (leaky-)ReLU same/head conv only")

@@ -13,8 +13,10 @@ generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 19
 and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
 ``to_rgb_mode`` (network.py:173-187), ``spectral`` in either network (spectral norm of every conv weight,
 layers.py:170-171) and ``conv_only`` (fully convolutional networks: k-tap layers in place of the full-length ones, the
-critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554), and ``act_norm='batch'`` in the critic
-(differentiated twice under the gradient penalty).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
+critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554), ``act_norm='batch'`` in the critic
+(differentiated twice under the gradient penalty) and ``num_classes`` (class scores y [B, classes] into the generator's
+batch norms through a shared embedding, network.py:284-292, 355-361, and into the critic's projection term, 518-523,
+555-557).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
 either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x': ...}``).
 """
 from __future__ import annotations
@@ -23,6 +25,7 @@ import numpy as np
 from torch import nn
 
 from . import ops
+from ._lib import ACT_NONE
 from .layers import ConcatResidual, ConditionalBatchNorm, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh, SelfAttention
 from .utils import pixel_norm, resample_signal
 
@@ -114,7 +117,7 @@ class Generator(nn.Module):
                  act_norm="pixel", conv_only=False, shared_embedding_size=32, normalize_latents=True,
                  rgb_generation_mode="pggan"):
         super().__init__()
-        _require(num_classes == 0, "conditioning")
+        _require(num_classes == 0 or act_norm == "batch", "class conditioning without batch norm layers")
         _require(not conv_only or not (z_to_bn or split_z), "conv_only with z_to_bn / split_z")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         _require(not per_channel_noise, "per_channel_noise")
@@ -144,10 +147,19 @@ class Generator(nn.Module):
         if latent_size is None:
             latent_size = nf(0)
         self.input_latent_size = latent_size
+        # (network.py:284-292) the classes enter every batch norm through one shared linear embedding
+        if num_classes != 0:
+            if shared_embedding_size > 0:
+                self.y_encoder = GeneralConv(num_classes, shared_embedding_size, kernel_size=1, equalized=False,
+                                             act_alpha=-1, spectral=False, bias=False)
+                num_classes = shared_embedding_size
+            else:
+                self.y_encoder = nn.Identity()
+        else:
+            self.y_encoder = None
         if self.split_z:  # network.py:294-295: one share of the latent per block plus one for the first layer's input
             latent_size //= stages + 2
         self.latent_size = latent_size
-        self.y_encoder = None
         block_settings = dict(ch_rgb=num_rgb_channels, k_size=kernel_size, is_residual=residual, deep=deep,
                               no_tanh=no_tanh, per_channel_noise=per_channel_noise, to_rgb_mode=to_rgb_mode)
         layer_settings = dict(z_to_bn_size=latent_size if z_to_bn else 0, equalized=equalized, spectral=spectral,
@@ -189,8 +201,12 @@ class Generator(nn.Module):
 
     def forward(self, z, y=None):
         if isinstance(z, dict):
-            z = z["z"]
-        _require(y is None, "conditional generation")
+            z, y = z["z"], z.get("y", y)
+        if y is not None:  # (network.py:355-361) class scores [B, classes] -> the shared embedding [B, E, 1]
+            if self.y_encoder is None:
+                y = None
+            else:
+                y = self.y_encoder(y.unsqueeze(2) if y.dim() == 2 else y)
         if self.normalize_latents:
             z = pixel_norm(z)
         if self.conv_only and z.dim() != 3:
@@ -209,24 +225,24 @@ class Generator(nn.Module):
         maps = {}  # attention maps by stage; the newest stage never gets the layer (network.py:383-390)
         if self.rgb_generation_mode != "pggan":
             saved = []
-            h = self.block0(h, None, zs(-1))
+            h = self.block0(h, y, zs(-1))
             saved.append(self.block0.to_rgb(h))
             for i in range(d):
-                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None), None, zs(i))
+                h = self.blocks[i](self._grow(h, i, maps if i < d - 1 else None), y, zs(i))
                 saved.append(self.blocks[i].to_rgb(h))
-            return {"x": self._combine_rgbs(saved), "y": None}, maps
+            return {"x": self._combine_rgbs(saved), "y": y}, maps
         if d == 0:
-            return {"x": self.block0(h, None, zs(-1), last=True), "y": None}, maps
-        h = self.block0(h, None, zs(-1))
+            return {"x": self.block0(h, y, zs(-1), last=True), "y": y}, maps
+        h = self.block0(h, y, zs(-1))
         for i in range(d - 1):
-            h = self.blocks[i](self._grow(h, i, maps), None, zs(i))
+            h = self.blocks[i](self._grow(h, i, maps), y, zs(i))
         h = self._grow(h, d - 1)
-        ult = self.blocks[d - 1](h, None, zs(d - 1), last=True)
+        ult = self.blocks[d - 1](h, y, zs(d - 1), last=True)
         if self.alpha == 1.0:
-            return {"x": ult, "y": None}, maps
+            return {"x": ult, "y": y}, maps
         prev = self.blocks[d - 2] if d > 1 else self.block0
         alpha = self.alpha_dev if self.alpha_dev is not None else self.alpha
-        return {"x": ops.blend(ult, prev.to_rgb(h), alpha), "y": None}, maps
+        return {"x": ops.blend(ult, prev.to_rgb(h), alpha), "y": y}, maps
 
 
 class DBlock(nn.Module):
@@ -278,7 +294,7 @@ class Discriminator(nn.Module):
                  temporal_groups_per_window=1, conv_only=False, input_to_all_layers=False, initial_sampling_rate=1.0,
                  sinc=False):
         super().__init__()
-        _require(num_classes == 0 and not sinc, "conditioning/sinc")
+        _require(not sinc, "sinc")
         _require(act_norm in (None, "batch"), "an activation norm other than 'batch' in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
@@ -312,7 +328,12 @@ class Discriminator(nn.Module):
         self.blocks = nn.ModuleList(
             [DBlock(nf(i + 2), nf(i + 1), sample_rate=lens[i + 1] * initial_sampling_rate / initial_kernel_size,
                     **block_settings, **layer_settings) for i in range(stages - 1, -1, -1)] + [last_block])
+        # (network.py:518-523) projection critic: a linear embedding of the classes, multiplied into the features
         self.class_emb = None
+        if num_classes != 0:
+            self.class_emb = nn.Linear(num_classes, nf(0), False)
+            if spectral:
+                self.class_emb = nn.utils.spectral_norm(self.class_emb)
         self.linear = GeneralConv(nf(0), 1, kernel_size=1, equalized=equalized, act_alpha=-1, spectral=spectral,
                                   init=init)
         self.max_depth = len(self.blocks) - 1
@@ -326,8 +347,7 @@ class Discriminator(nn.Module):
     def forward(self, x, y=None):
         """``x``: a batch (tensor or {'x': tensor}) -> (scores, features, {})."""
         if isinstance(x, dict):
-            x = x["x"]
-        _require(y is None, "conditional discrimination")
+            x, y = x["x"], x.get("y", y)
         d = self.depth
         maps = {}
         h = self.blocks[-(d + 1)](x, True)
@@ -356,4 +376,20 @@ class Discriminator(nn.Module):
         if o.shape[2] != 1:  # (network.py:554) the mean over time, as a product with a constant vector
             ones = o.new_ones((o.shape[0], o.shape[2], 1))
             o = ops.bmm(o, ones, alpha=1.0 / o.shape[2])
-        return o.reshape(o.shape[0]), h, maps
+        o = o.reshape(o.shape[0])
+        if y is not None:
+            # (network.py:555-557) + sum_c emb[b, c] * mean_t h[b, c, t]: the embedding as a 1x1 layer on the class
+            # scores, the sum as a batched product (both twice differentiable)
+            if self.class_emb is None:
+                raise ValueError("this critic was built without classes")
+            emb_w = self.class_emb
+            if hasattr(emb_w, "weight_orig"):
+                w, _ = ops.spectral_norm(emb_w.weight_orig, emb_w.weight_u, emb_w.weight_v, 1e-12, self.training)
+            else:
+                w = emb_w.weight
+            emb = ops.conv1d(y.reshape(y.shape[0], -1, 1).contiguous(), w.unsqueeze(2), None, None, 1.0, ACT_NONE)
+            proj = ops.bmm(emb, h, trans_a=True, alpha=1.0 / h.shape[2])  # [B, 1, T]
+            if proj.shape[2] != 1:
+                proj = ops.bmm(proj, proj.new_ones((proj.shape[0], proj.shape[2], 1)))
+            o = ops.axpby(o, 1.0, proj.reshape(proj.shape[0]), 1.0)
+        return o, h, maps

@@ -218,24 +218,31 @@ def has_layer(params, prefix: str) -> bool:
     return f"{prefix}.weight" in params or f"{prefix}.weight_orig" in params
 
 
-def conditional_batch_norm(x, params, scales, prefix: str, z=None):
+def conditional_batch_norm(x, params, scales, prefix: str, z=None, y=None):
     """ConditionalBatchNorm.forward in training mode, layers.py:117-134: statistics of the batch over (batch, time);
-    'BN' mode (affine normaliser) when the layer has no modulation network, else 'SM': a normaliser without affine
-    parameters, then out + gamma * out + beta with (gamma, beta) = the two halves of a two-layer 1x1 network (ReLU in
-    between, layers.py:107-111) on the latent [B, latent, 1], repeated over time."""
+    'BN' mode (affine normaliser) when the layer has no modulation network, else a normaliser without affine
+    parameters, then out + gamma * out + beta with (gamma, beta) = the two halves of the modulation network's output,
+    repeated over time: 'CBN' a linear 1x1 layer on the class embedding y [B, E, 1]; 'SM' a two-layer 1x1 network
+    (ReLU in between, layers.py:107-111) on the latent [B, latent, 1]; 'CSM' the same on [latent; y] stacked along the
+    channels."""
     out = F.batch_norm(x, None, None, params.get(f"{prefix}.normalizer.weight"), params.get(f"{prefix}.normalizer.bias"),
                        training=True, eps=1e-5)
-    if not has_layer(params, f"{prefix}.embed.0.conv.conv"):
+    if has_layer(params, f"{prefix}.embed.conv.conv"):  # 'CBN'
+        e = general_conv(y, params, scales, f"{prefix}.embed", act_alpha=-1)
+    elif has_layer(params, f"{prefix}.embed.0.conv.conv"):
+        z3 = z.unsqueeze(2) if z.dim() == 2 else z
+        cond = z3 if y is None else torch.cat([resample(z3, z3.shape[2], y.shape[2]), y], dim=1)  # 'SM' | 'CSM'
+        e = general_conv(cond, params, scales, f"{prefix}.embed.0", act_alpha=0.0)
+        e = general_conv(e, params, scales, f"{prefix}.embed.1", act_alpha=-1)
+    else:
         return out
-    e = general_conv(z, params, scales, f"{prefix}.embed.0", act_alpha=0.0)
-    e = general_conv(e, params, scales, f"{prefix}.embed.1", act_alpha=-1)
     e = resample(e, e.shape[2], out.shape[2])
     gamma, beta = e.chunk(2, dim=1)
     return out + gamma * out + beta
 
 
 def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None, drop=0.0,
-                 src: Optional[DropSource] = None, z=None):
+                 src: Optional[DropSource] = None, z=None, y=None):
     """layers.py:207-213 for the default options: conv -> LeakyReLU ->
     (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
     if has_layer(params, f"{path}.conv.net.0.conv"):
@@ -254,7 +261,7 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
         pad = (k - 1) // 2 if pad is None else pad
         h = equalized_conv1d(x, w, b, scales[path], pad)
     if norm == "batch":  # layers.py:211-212: between conv and activation
-        h = conditional_batch_norm(h, params, scales, f"{path}.norm", z)
+        h = conditional_batch_norm(h, params, scales, f"{path}.norm", z, y)
     if act_alpha >= 0:
         h = leaky_relu(h, act_alpha) if act_alpha > 0 else F.relu(h)
     if norm == "pixel":
@@ -356,11 +363,11 @@ def minibatch_stddev(x, group_size: int = 4, window: int = 32):
 
 # --------------------------------------------------------------------------- networks
 def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", first: bool = False,
-            last: bool = False, z=None):
+            last: bool = False, z=None, y=None):
     """GBlock.forward, network.py:206-218 (no residual, not deep): two GeneralConvs with pixel norm and
     GDrop, the first one with the full-length kernel and pad = k-1 in the first block (network.py:157-159);
     ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
-    ls = dict(act_alpha=cfg.act_alpha, norm=cfg.g_act_norm, drop=cfg.g_dropout, src=src, z=z)
+    ls = dict(act_alpha=cfg.act_alpha, norm=cfg.g_act_norm, drop=cfg.g_dropout, src=src, z=z, y=y)
     x = h
     first = first and not cfg.g_conv_only  # (network.py:35, 303: a fully convolutional generator has no full-length layer)
     h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
@@ -449,14 +456,14 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
 
 
 def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfig,
-                      src: Optional[DropSource] = None):
+                      src: Optional[DropSource] = None, y=None):
     """network.py:354-396 (default options: pggan rgb mode, pixel norm,
     normalize_latents, no conditioning).  Returns x[B, 5, T(depth)]."""
     src = src or DropSource("off")
 
     def gblock(prefix, h, first=False):
         layer = -1 if first else int(prefix.split(".")[1])
-        return g_block(params, scales, prefix, h, cfg, src, first=first, z=z_of(layer))
+        return g_block(params, scales, prefix, h, cfg, src, first=first, z=z_of(layer), y=y)
 
     def to_rgb(prefix, h):
         return g_to_rgb(params, scales, prefix, h, cfg)
@@ -466,6 +473,10 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
             return self_attention(params, scales, f"dummy.{list(cfg.self_attention_layers).index(layer)}", h)[0]
         return h
 
+    if y is not None:  # network.py:355-361, 284-292: class scores [B, classes] -> the shared embedding [B, E, 1]
+        y = y.unsqueeze(2) if y.dim() == 2 else y
+        if has_layer(params, "y_encoder.conv.conv"):
+            y = general_conv(y, params, scales, "y_encoder", act_alpha=-1)
     h = pixel_norm(z) if cfg.normalize_latents else z
     if h.dim() == 2:  # (network.py:364-367: a fully convolutional generator is given [B, latent, L])
         h = h.unsqueeze(2)
@@ -511,7 +522,7 @@ def generator_forward(params, scales, z, depth: int, alpha: float, cfg: NetConfi
 
 
 def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetConfig,
-                          src: Optional[DropSource] = None):
+                          src: Optional[DropSource] = None, y=None):
     """network.py:528-560 (default options).  Returns (score[B], h[B, 256, 1])."""
     src = src or DropSource("off")
     R = cfg.num_stages
@@ -544,8 +555,11 @@ def discriminator_forward(params, scales, x, depth: int, alpha: float, cfg: NetC
                 h = (h + from_rgb(R + 2 - i, x_low)) / 2.0
         if (i - 2) in cfg.self_attention_layers:  # network.py:550-553
             h = self_attention(params, scales, f"dummy.{list(cfg.self_attention_layers).index(i - 2)}", h)[0]
-    o = general_conv(h, params, scales, "linear", act_alpha=-1)
-    return o.mean(dim=2).squeeze(), h
+    o = general_conv(h, params, scales, "linear", act_alpha=-1).mean(dim=2).squeeze()
+    if y is not None:  # network.py:555-557: projection on a linear embedding of the classes
+        w = layer_weight(params, "class_emb")
+        o = o + ((y @ w.t()).unsqueeze(2) * h).mean(dim=2).sum(dim=1)
+    return o, h
 
 
 # --------------------------------------------------------------------------- losses

@@ -134,7 +134,7 @@ def test_oracle_matches_reference(name):
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
     for kw in (dict(generator=dict(per_channel_noise=True)), dict(discriminator=dict(sinc=True)),
-               dict(discriminator=dict(act_norm="pixel")), dict(shared=dict(num_classes=10))):
+               dict(discriminator=dict(act_norm="pixel")), dict(shared=dict(num_classes=10))):  # (classes need batch norms)
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
