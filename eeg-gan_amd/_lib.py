@@ -75,6 +75,8 @@ SIGNATURES = {
     "eeggan_channel_sum": (_i, [_f, _f, _i, _i, _i, _fl, _st]),
     "eeggan_channel_affine": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
     "eeggan_product": (_i, [_f, _f, _f, _sz, _st]),
+    "eeggan_position_sum": (_i, [_f, _f, _i, _i, _i, _fl, _st]),
+    "eeggan_position_scale": (_i, [_f, _f, _f, _i, _i, _i, _st]),
     "eeggan_spectral_norm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _fl, _i, _st]),
     "eeggan_spectral_norm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _i, _st]),
     "eeggan_bn_lrelu_drop_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _fl, _fl, _fl, _i, _st]),

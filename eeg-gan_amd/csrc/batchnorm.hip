@@ -185,10 +185,50 @@ __global__ __launch_bounds__(256) void product_kernel(const float* __restrict__ 
     if (i < n) out[i] = a[i] * b[i];
 }
 
+// ---- the same for sums over the channels per (sample, time step): the pieces of a pixel norm that is differentiated twice
+__global__ __launch_bounds__(256) void position_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T,
+                                                           float scale, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over (b, t)
+    if (i >= n) return;
+    const long long b = i / T;
+    const int t = (int)(i - b * T);
+    const float* p = x + b * C * T + t;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += p[(long long)c * T];
+    out[i] = s * scale;
+}
+
+// y[b, c, t] = x[b, c, t] * s[b, t]   (x NULL: y = s[b, t])
+__global__ __launch_bounds__(256) void position_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             float* __restrict__ y, int C, int T, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long row = i / T;  // b * C + c
+    const int t = (int)(i - row * T);
+    const float v = s[(row / C) * T + t];
+    y[i] = x ? x[i] * v : v;
+}
+
 }  // namespace
 }  // namespace eeggan
 
 using namespace eeggan;
+
+extern "C" int eeggan_position_sum(const float* x, float* out, int B, int C, int T, float scale, void* stream) {
+    EEGGAN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "position_sum: bad arguments");
+    const long long n = (long long)B * T;
+    hipLaunchKernelGGL(position_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, out, C, T,
+                       scale, n);
+    return check_launch("position_sum");
+}
+
+extern "C" int eeggan_position_scale(const float* x, const float* s, float* y, int B, int C, int T, void* stream) {
+    EEGGAN_REQUIRE(s && y && B > 0 && C > 0 && T > 0, "position_scale: bad arguments");
+    const long long n = (long long)B * C * T;
+    hipLaunchKernelGGL(position_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, s, y, C, T,
+                       n);
+    return check_launch("position_scale");
+}
 
 extern "C" int eeggan_channel_sum(const float* x, float* out, int B, int C, int T, float scale, void* stream) {
     EEGGAN_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "channel_sum: bad arguments");

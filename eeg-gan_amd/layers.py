@@ -454,6 +454,10 @@ class GeneralConv(nn.Module):
             net.append(self.drop)
         self.net = nn.Sequential(*net)  # parameter-less; kept for module-tree parity
 
+    # the critic's layers are differentiated twice (gradient penalty): the Discriminator sets this, and a pixel norm
+    # then runs as a chain of multilinear pieces instead of inside the first-order fused layer
+    second_order = False
+
     def _multipliers(self, x):
         if self.drop is None:
             return None
@@ -491,6 +495,18 @@ class GeneralConv(nn.Module):
                 xin = x.squeeze(2) if kind == "head" else x
                 c_lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
             return self.norm.apply_with(c_lin, z, self._multipliers(x), slope if self.act_alpha >= 0 else 1.0, y=y)
+        if self.act_norm == "pixel" and self.second_order:
+            # the critic (everything twice differentiable): conv + (leaky) ReLU, the norm from multilinear pieces,
+            # then the multipliers
+            if kind == "same":
+                a = ops.conv1d(x, w, b, None, s, ACT_LRELU if self.act_alpha >= 0 else ACT_NONE, slope, flip=c._flip)
+            elif kind == "tail":
+                a = ops.tail_conv(x, w, b, None, s, slope if self.act_alpha >= 0 else 1.0)
+            else:
+                raise NotImplementedError("pixel norm after a length-1 (head) conv in the critic")
+            y_ = ops.pixel_norm_twice(a)
+            drop = self._multipliers(x)
+            return y_ if drop is None else ops.lrelu_drop(y_, drop, 1.0)
         if self.act_norm == "pixel":
             if self.act_alpha < 0 or kind == "tail":
                 raise NotImplementedError("pixel norm is fused with a (leaky-)ReLU same/head conv only")

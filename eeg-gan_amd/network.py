@@ -13,7 +13,7 @@ generator ``act_norm='batch'`` with or without ``z_to_bn`` (layers.py:93-134, 19
 and ``split_z`` (network.py:270-272, 294-295, 317-322, 368-371) and the 'sngan' / 'sagan' / 'biggan' forms of
 ``to_rgb_mode`` (network.py:173-187), ``spectral`` in either network (spectral norm of every conv weight,
 layers.py:170-171) and ``conv_only`` (fully convolutional networks: k-tap layers in place of the full-length ones, the
-critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554), ``act_norm='batch'`` in the critic
+critic's score the mean over time; network.py:33-36, 364-365, 416-418, 554), ``act_norm='batch'`` / ``'pixel'`` in the critic
 (differentiated twice under the gradient penalty) and ``num_classes`` (class scores y [B, classes] into the generator's
 batch norms through a shared embedding, network.py:284-292, 355-361, and into the critic's projection term, 518-523,
 555-557).  Any other option raises ``NotImplementedError`` in the constructor.  ``forward`` accepts
@@ -295,7 +295,7 @@ class Discriminator(nn.Module):
                  sinc=False):
         super().__init__()
         _require(not sinc, "sinc")
-        _require(act_norm in (None, "batch"), "an activation norm other than 'batch' in the discriminator")
+        _require(act_norm in (None, "batch", "pixel"), f"act_norm={act_norm!r} in the discriminator")
         assert len(progression_scale_up) == len(progression_scale_down)
         stages = len(progression_scale_up)
         self.progression_scale_up = progression_scale_up
@@ -337,8 +337,8 @@ class Discriminator(nn.Module):
         self.linear = GeneralConv(nf(0), 1, kernel_size=1, equalized=equalized, act_alpha=-1, spectral=spectral,
                                   init=init)
         self.max_depth = len(self.blocks) - 1
-        for m in self.modules():  # (batch norms under the gradient penalty are differentiated twice)
-            if isinstance(m, ConditionalBatchNorm):
+        for m in self.modules():  # (the layers' norms are differentiated twice under the gradient penalty)
+            if isinstance(m, (ConditionalBatchNorm, GeneralConv)):
                 m.second_order = True
 
     def _shrink(self, h, stage):

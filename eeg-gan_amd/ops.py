@@ -1099,6 +1099,61 @@ class _Product(Function):
                 _Product.apply(g, a) if ctx.needs_input_grad[1] else None)
 
 
+class _PosSum(Function):
+    """[B, C, T] -> [B, 1, T]: scale * the sum over the channels."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _chk(x, "position sum input")
+        B, C, T = x.shape
+        out = torch.empty((B, 1, T), device=x.device, dtype=torch.float32)
+        call("eeggan_position_sum", x.data_ptr(), out.data_ptr(), B, C, T, float(scale), _stream())
+        ctx.cfg = (C, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C, scale = ctx.cfg
+        return _PosScale.apply(None, g.contiguous() * scale, C), None
+
+
+class _PosScale(Function):
+    """x * s with s [B, 1, T] spread over the channels (x None: s spread over ``C`` channels)."""
+
+    @staticmethod
+    def forward(ctx, x, s, C):
+        s = _chk(s, "position scale factor")
+        B, _, T = s.shape
+        if x is not None:
+            x = _chk(x, "position scale input")
+            if tuple(x.shape) != (B, C, T):
+                raise RuntimeError(f"position scale: input {tuple(x.shape)} is not {(B, C, T)}")
+        y = torch.empty((B, C, T), device=s.device, dtype=torch.float32)
+        call("eeggan_position_scale", _p(x), s.data_ptr(), y.data_ptr(), B, C, T, _stream())
+        ctx.save_for_backward(x, s)
+        ctx.C = C
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gs = None
+        if x is not None and ctx.needs_input_grad[0]:
+            gx = _PosScale.apply(g, s, ctx.C)
+        if ctx.needs_input_grad[1]:
+            gs = _PosSum.apply(_Product.apply(g, x), 1.0) if x is not None else _PosSum.apply(g, 1.0)
+        return gx, gs, None
+
+
+def pixel_norm_twice(a, eps=1e-8):
+    """a / sqrt(mean over the channels of a^2 + eps) (PixelNorm, reference layers.py:10-14), differentiable to any
+    order; the per-position vector in between is handled with torch's own operations."""
+    C = a.shape[1]
+    mean_sq = _PosSum.apply(_Product.apply(a, a), 1.0 / C)
+    return _PosScale.apply(a, (mean_sq + eps).rsqrt(), C)
+
+
 def batch_norm_twice(c, gamma, beta, run_mean, run_var, eps, momentum, train):
     """gamma * normalise(c) + beta with statistics over (batch, time) per channel (biased variance; evaluation mode:
     the running ones), differentiable to any order.  The per-channel vectors in between are handled with torch's

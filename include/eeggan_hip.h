@@ -320,6 +320,13 @@ int eeggan_channel_affine(const float* x, const float* s, const float* t, float*
 /* out = a * b elementwise. */
 int eeggan_product(const float* a, const float* b, float* out, size_t count, void* stream);
 
+/* The same for a pixel norm that is differentiated twice (act_norm = 'pixel' in the Discriminator; PixelNorm,
+ * layers.py:10-14): sums over the channels per (sample, time step) and a per-position scale. */
+/* out[b, t] = scale * sum over ch of x[b, ch, t]. */
+int eeggan_position_sum(const float* x, float* out, int B, int C, int T, float scale, void* stream);
+/* y[b, ch, t] = x[b, ch, t] * s[b, t]   (x NULL: y = s[b, t]). */
+int eeggan_position_scale(const float* x, const float* s, float* y, int B, int C, int T, void* stream);
+
 /* ---- spectral normalisation of a weight (torch.nn.utils.spectral_norm as layers.py:170-171 and network.py:520-521
  * apply it): the weight as a matrix W [rows = output channels, cols = the other dimensions]. -------------------- */
 /* power_iteration != 0 (training): v <- normalize(W^T u), u <- normalize(W v) in place (normalize(x) = x / max(|x|, eps));

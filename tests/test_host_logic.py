@@ -42,7 +42,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True, "split_z": True})
     with pytest.raises(NotImplementedError):
-        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "pixel"})
+        Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "layer"})
     with pytest.raises(NotImplementedError):  # (classes enter the generator through its batch norms only)
         Generator(**{**kw, "num_classes": 10}, z_distribution="normal", **config.GENERATOR_KWARGS)
     with pytest.raises(NotImplementedError):

@@ -46,6 +46,7 @@ CASES = {
     "conv_only_d": dict(shared=dict(residual=True), discriminator=dict(conv_only=True)),
     "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True)),
     "d_batch_norm": dict(discriminator=dict(act_norm="batch")),
+    "d_pixel_norm": dict(discriminator=dict(act_norm="pixel")),
 }
 
 
@@ -134,7 +135,7 @@ def test_oracle_matches_reference(name):
 def test_options_outside_the_supported_set_still_raise():
     from eeggan_amd import config
     for kw in (dict(generator=dict(per_channel_noise=True)), dict(discriminator=dict(sinc=True)),
-               dict(discriminator=dict(act_norm="pixel")), dict(shared=dict(num_classes=10))):  # (classes need batch norms)
+               dict(discriminator=dict(act_norm="layer")), dict(shared=dict(num_classes=10))):  # (classes need batch norms)
         with pytest.raises(NotImplementedError):
             config.build_models(1, **kw)
     with pytest.raises(ValueError):
@@ -581,3 +582,27 @@ def test_graph_trainer_with_batch_norm_critic(dev):
         E._same_trajectory(base, graphed, "graph replay, batch norm critic", moment_tol=5e-5)
     finally:
         layers.set_drop_mode("numpy")
+
+
+@pytest.mark.gpu
+def test_pixel_norm_to_second_order(dev):
+    """The critic's pixel norm (multilinear pieces) against float64 torch: values, first derivatives and the
+    derivatives of a penalty on the input gradient."""
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    B, C, T = 5, 24, 40
+    a = torch.randn(B, C, T, generator=gen)
+    q = torch.randn(B, C, T, generator=gen)
+
+    def run(dt, device, fn):
+        aa = a.to(device, dt).requires_grad_(True)
+        y = fn(aa)
+        (ga,) = torch.autograd.grad(y, aa, q.to(device, dt), create_graph=True)
+        pen = ((ga * ga).sum(dim=(1, 2)).sqrt() - 1.0).pow(2).sum() + (y * y * y).mean()
+        (gp,) = torch.autograd.grad(pen, aa)
+        return y, ga, gp
+
+    ref = run(torch.float64, "cpu", lambda h: h * torch.rsqrt((h * h).mean(dim=1, keepdim=True) + 1e-8))
+    got = run(torch.float32, dev, ops.pixel_norm_twice)
+    for name, x, r in zip(("y", "input gradient", "d pen / d a"), got, ref):
+        assert rel(x, r) < 5e-5, (name, rel(x, r))

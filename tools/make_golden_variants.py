@@ -5,7 +5,7 @@ REFERENCE implementation (see make_golden.py for how it is imported and what is 
 Cases: residual blocks, the generator's 'residual' and 'mean' signal modes (mid fade-in and at alpha = 1), the
 critic's input at every stage, plain layers (ReLU, no equalization, xavier init, no tanh, latents not normalised),
 separable layers, deep blocks, self attention (wide and narrow stages), batch norm in the generator (plain and
-modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, fully convolutional networks, batch norm in the critic, and the generator loss's random multiplier
+modulated by the latent), the 'sngan' / 'sagan' / 'biggan' forms of to_rgb, spectral norm in either network, fully convolutional networks, batch norm and pixel norm in the critic, and the generator loss's random multiplier
 and feature-matching term.  Every case records one critic and one
 generator loss evaluation in fp64 and fp32 (values, fakes, scores, all parameter gradients), after this
 repository's modules were checked to initialise bit-identically and the CPU restatement to reproduce the fp64 run.
@@ -63,6 +63,9 @@ CASES = {
     "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True), depth=2, alpha=1.0, z_len=32),
     # batch norm in the critic's layers: differentiated twice under the gradient penalty
     "d_batch_norm": dict(discriminator=dict(act_norm="batch"), depth=2, alpha=0.6),
+    # (depth 2 at alpha 1 was tried first: one pre-activation of the critic lies within 5e-7 of zero there, and the
+    # fp32 rounding of the fakes flips its LeakyReLU -- 5e-3 on that sample's input gradient in pure fp64 arithmetic)
+    "d_pixel_norm": dict(discriminator=dict(act_norm="pixel"), depth=3, alpha=0.7),
 }
 
 
