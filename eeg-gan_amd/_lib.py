@@ -48,6 +48,8 @@ SIGNATURES = {
     "eeggan_head_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_head_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_tail_fwd": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, _st]),
+    "eeggan_tail_fwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "eeggan_tail_fwd_ws": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _i, _fl, _i, _fl, C.c_void_p, _sz, _st]),
     "eeggan_tail_dgrad": (_i, [_f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_tail_wgrad": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _fl, _st]),
     "eeggan_lrelu_drop_bwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _st]),

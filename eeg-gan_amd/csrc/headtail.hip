@@ -7,6 +7,7 @@
 // with the weight streamed coalesced and the small operand broadcast from LDS (the head's forward pass and the
 // tail's input gradient run on the matrix cores).
 #include "common.h"
+#include "conv_args.h"
 
 #include <cstdlib>
 
@@ -442,6 +443,108 @@ __global__ __launch_bounds__(256) void tail_dgrad_mfma_kernel(const float* __res
     }
 }
 
+// Forward of the full-length layer as a product [B, Kd] x [Kd, Cout] with the reduction split over workgroups:
+// grid (sample tiles x channel tiles, splits); a workgroup owns a 32 x 32 tile of (samples, channels) and Kd / splits
+// reduction indices, its four waves a quarter of those each.  A lane reads 16 consecutive floats of its sample's and of
+// its channel's row per step (a wave: whole 128-byte lines of 32 + 32 rows), the fp32 matrix instruction pairs element e
+// of the lower half-wave with element e of the upper one.  The four waves' tiles meet in LDS; the partial tile goes to
+// part[split][b][co] and tail_fwd_reduce_kernel sums the splits in order and applies the epilogue.  (The weights are
+// 8 MB read once: at 256 workgroups every CU streams 32 KB of them instead of a workgroup re-reading rows through L2.)
+constexpr int TFM_STEP = 32;  // reduction indices per wave and step
+
+__global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ part, int B, int Kd, int Cout, int tiles_co,
+                                                            int krange) {
+    __shared__ float red[4 * 1024];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int tb = blockIdx.x / tiles_co, tc = blockIdx.x - tb * tiles_co;
+    const int split = blockIdx.y;
+    const int b = tb * 32 + l31 < B ? tb * 32 + l31 : B - 1;
+    const int co = tc * 32 + l31;  // (Cout % 32 == 0)
+    const int kq = krange / 4;     // per wave; a multiple of TFM_STEP
+    const int k0 = split * krange + wave * kq + 16 * h;
+    const float* xp = x + (long long)b * Kd + k0;
+    const float* wp = w + (long long)co * Kd + k0;
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    // Up to four steps' loads (a wave's whole share at 64 samples) are issued before the first matrix instruction: the
+    // launch is a single trip to memory plus the instructions, not a chain of trips.
+    constexpr int GROUP = 4;
+    for (int k = 0; k < kq; k += GROUP * TFM_STEP) {
+        f32x4 xv[GROUP][4], wv[GROUP][4];
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            const int kk = k + g * TFM_STEP < kq ? k + g * TFM_STEP : k;  // (past the share: a valid address, unused)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xv[g][i] = *reinterpret_cast<const f32x4*>(xp + kk + 4 * i);
+                wv[g][i] = *reinterpret_cast<const f32x4*>(wp + kk + 4 * i);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GROUP; ++g) {
+            if (k + g * TFM_STEP < kq) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[g][i][e], wv[g][i][e], acc[0], 0, 0, 0);
+            }
+        }
+    }
+    float sums[4];
+    cross_wave_sum<1>(acc, red, sums);
+    float* out = part + (long long)split * B * Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = threadIdx.x + 256 * i;
+        const int r = (v >> 6) & 15, ln = v & 63;
+        const int bo = tb * 32 + acc_row(r, ln >> 5);
+        if (bo < B) out[(long long)bo * Cout + tc * 32 + (ln & 31)] = sums[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_fwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              const float* __restrict__ drop, float* __restrict__ y, int n,
+                                                              int Cout, int splits, float in_scale, int act,
+                                                              float act_param) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // (the splits in order, eight loads in flight: one at a time this loop is a chain of trips to memory)
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long long)(k + u) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += part[(long long)k * n + i];
+    const int co = i % Cout;
+    float v = apply_act(s * in_scale + (bias ? bias[co] : 0.f), act, act_param);
+    if (drop) v *= drop[i];
+    y[i] = v;
+}
+
+// splits of the reduction for the matrix-core forward: enough workgroups for the chip, whole steps per wave
+int tail_fwd_splits(int B, int Kd, int Cout) {
+    const int tiles = ((B + 31) / 32) * (Cout / 32);
+    int s = 1;
+    while (s * 2 * tiles <= num_cus() && Kd % (s * 2 * 4 * TFM_STEP) == 0) s *= 2;
+    return s;
+}
+
+// (comparison switch: EEGGAN_TAIL_MFMA=0 keeps the forward on the vector-ALU kernel)
+bool tail_fwd_mfma_shape(int Kd, int Cout) {
+    static const bool on = [] {
+        const char* e = getenv("EEGGAN_TAIL_MFMA");
+        return !(e && e[0] == '0');
+    }();
+    return on && Kd % (4 * TFM_STEP) == 0 && Cout % 32 == 0;
+}
+
 bool tail_mfma_shape(int Kd, int Cout) { return Kd % 32 == 0 && Cout % 32 == 0; }
 
 int check_ht(const char* what, int B, int Cin, int Cout, int KT) {
@@ -498,6 +601,36 @@ extern "C" int eeggan_tail_fwd(const float* x, const float* w, const float* bias
     hipLaunchKernelGGL(tail_fwd_kernel, dim3((Cout + 3) / 4, (B + 7) / 8), dim3(256), 0, as_stream(stream), x, w, bias,
                        drop, y, B, Kd, Cout, in_scale, act, act_param);
     return check_launch("tail_fwd");
+}
+
+extern "C" size_t eeggan_tail_fwd_workspace(int B, int Cin, int Cout, int KT) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || KT <= 0) return 0;
+    const int Kd = Cin * KT;
+    if (!tail_fwd_mfma_shape(Kd, Cout)) return 0;
+    return (size_t)tail_fwd_splits(B, Kd, Cout) * B * Cout * sizeof(float);
+}
+
+extern "C" int eeggan_tail_fwd_ws(const float* x, const float* w, const float* bias, const float* drop, float* y, int B,
+                                  int Cin, int Cout, int KT, float in_scale, int act, float act_param, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (check_ht("tail_fwd", B, Cin, Cout, KT)) return 1;
+    EEGGAN_REQUIRE(x && w && y, "tail_fwd: null pointer");
+    const int Kd = Cin * KT;
+    const size_t need = eeggan_tail_fwd_workspace(B, Cin, Cout, KT);
+    if (need == 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) != 0)
+        return eeggan_tail_fwd(x, w, bias, drop, y, B, Cin, Cout, KT, in_scale, act, act_param, stream);
+    EEGGAN_REQUIRE(workspace && workspace_bytes >= need, "tail_fwd: workspace of %zu bytes needed, %zu given", need,
+                   workspace_bytes);
+    const int splits = tail_fwd_splits(B, Kd, Cout);
+    const int tiles_co = Cout / 32;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(tail_fwd_mfma_kernel, dim3((unsigned)(((B + 31) / 32) * tiles_co), (unsigned)splits), dim3(256), 0,
+                       as_stream(stream), x, w, part, B, Kd, Cout, tiles_co, Kd / splits);
+    if (check_launch("tail_fwd")) return 1;
+    const int n = B * Cout;
+    hipLaunchKernelGGL(tail_fwd_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), part, bias,
+                       drop, y, n, Cout, splits, in_scale, act, act_param);
+    return check_launch("tail_fwd reduce");
 }
 
 extern "C" int eeggan_tail_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, int Cout, int KT,

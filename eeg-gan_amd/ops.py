@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import functools
 import os
 import weakref
 from typing import Optional
@@ -799,9 +800,21 @@ def _tail_fwd_raw(x, w, bias, drop, in_scale, act, slope):
     B, Cin, KT = x.shape
     Cout = w.shape[0]
     y = torch.empty((B, Cout, 1), device=x.device, dtype=torch.float32)
-    call("eeggan_tail_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, KT,
-         float(in_scale), int(act), float(slope), _stream())
+    need = _tail_fwd_ws_bytes(B, Cin, Cout, KT)
+    if need:  # matrix-core form: the reduction is split over workgroups, partial sums go through a workspace
+        ws = torch.empty((need // 4,), device=x.device, dtype=torch.float32)
+        call("eeggan_tail_fwd_ws", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, KT,
+             float(in_scale), int(act), float(slope), ws.data_ptr(), need, _stream())
+    else:
+        call("eeggan_tail_fwd", x.data_ptr(), w.data_ptr(), _p(bias), _p(drop), y.data_ptr(), B, Cin, Cout, KT,
+             float(in_scale), int(act), float(slope), _stream())
     return y
+
+
+@functools.lru_cache(maxsize=None)
+def _tail_fwd_ws_bytes(B, Cin, Cout, KT):
+    from ._lib import load
+    return int(load().eeggan_tail_fwd_workspace(B, Cin, Cout, KT))
 
 
 def _tail_dgrad_raw(gc, w, in_scale):

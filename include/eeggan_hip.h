@@ -163,6 +163,13 @@ int eeggan_head_dgrad(const float* gy, const float* w, float* gz,
 int eeggan_tail_fwd(const float* x, const float* w, const float* bias, const float* drop, float* y,
                     int B, int Cin, int Cout, int KT, float in_scale, int act, float act_param,
                     void* stream);
+/* The same on the matrix cores with the reduction split over workgroups (Cin*KT a multiple of 128, Cout of 32, x and w
+ * 16-byte aligned; other shapes run eeggan_tail_fwd): partial sums go through ``workspace`` of at least
+ * eeggan_tail_fwd_workspace(...) bytes (0: the shape takes no workspace) and are summed in a fixed order. */
+size_t eeggan_tail_fwd_workspace(int B, int Cin, int Cout, int KT);
+int eeggan_tail_fwd_ws(const float* x, const float* w, const float* bias, const float* drop, float* y, int B, int Cin,
+                       int Cout, int KT, float in_scale, int act, float act_param, void* workspace, size_t workspace_bytes,
+                       void* stream);
 int eeggan_tail_dgrad(const float* gy, const float* w, float* gx,
                       int B, int Cin, int Cout, int KT, float in_scale, void* stream);
 int eeggan_tail_wgrad(const float* x, const float* gy, float* gw, float* gb,
