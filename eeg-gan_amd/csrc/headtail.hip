@@ -452,44 +452,80 @@ __global__ __launch_bounds__(256) void tail_dgrad_mfma_kernel(const float* __res
 // 8 MB read once: at 256 workgroups every CU streams 32 KB of them instead of a workgroup re-reading rows through L2.)
 constexpr int TFM_STEP = 32;  // reduction indices per wave and step
 
+constexpr int TFM_CHUNK = 4 * TFM_STEP;  // reduction indices a workgroup stages per round (a wave computes a quarter)
+constexpr int TFM_LD = TFM_CHUNK + 4;    // LDS row stride in floats (16-byte reads of 32 rows without bank conflicts)
+
 __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ part, int B, int Kd, int Cout, int tiles_co,
                                                             int krange) {
+    // Rows of x and w lie Kd floats (32 KB) apart: a matrix-instruction operand read straight from global memory
+    // touches 32 of them per load.  So the tile is staged: a wave's load instruction takes two whole 512-byte row
+    // segments (fully coalesced), the operands are read from LDS (one buffer, two barriers per chunk).
+    __shared__ __attribute__((aligned(16))) float tile[64 * TFM_LD];  // rows 0-31: samples, 32-63: channels
     __shared__ float red[4 * 1024];
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-    const int tb = blockIdx.x / tiles_co, tc = blockIdx.x - tb * tiles_co;
-    const int split = blockIdx.y;
-    const int b = tb * 32 + l31 < B ? tb * 32 + l31 : B - 1;
-    const int co = tc * 32 + l31;  // (Cout % 32 == 0)
-    const int kq = krange / 4;     // per wave; a multiple of TFM_STEP
-    const int k0 = split * krange + wave * kq + 16 * h;
-    const float* xp = x + (long long)b * Kd + k0;
-    const float* wp = w + (long long)co * Kd + k0;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  All tiles of one split read the
+    // same columns of x and w: with splits % 8 == 0 the linear id is re-read as (XCD, split within the XCD, tile), so a
+    // split's tiles share an L2 and its 32 + 32 row segments come over the fabric once instead of once per XCD.
+    const int tiles = gridDim.x, splits = gridDim.y;
+    int tile_id = blockIdx.x, split = blockIdx.y;
+    if (splits % 8 == 0) {
+        const int lin = blockIdx.x + tiles * blockIdx.y;
+        const int xcd = lin & 7, j = lin >> 3;
+        split = xcd * (splits >> 3) + j / tiles;
+        tile_id = j - (j / tiles) * tiles;
+    }
+    const int tb = tile_id / tiles_co, tc = tile_id - tb * tiles_co;
+    const int kbase = split * krange;
+    // staging: thread -> (row pair, 16-byte column); wave `wave` takes rows 16 wave .. 16 wave + 15 of the 64
+    const int s_col = 4 * l31;  // float offset within the 128-float segment
+    const float* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 16 * wave + 2 * i + h;  // 0 .. 63
+        if (row < 32) {
+            const int b = tb * 32 + row < B ? tb * 32 + row : B - 1;
+            src[i] = x + (long long)b * Kd + kbase + s_col;
+        } else {
+            src[i] = w + (long long)(tc * 32 + row - 32) * Kd + kbase + s_col;
+        }
+    }
     f32x16 acc[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-    // Up to four steps' loads (a wave's whole share at 64 samples) are issued before the first matrix instruction: the
-    // launch is a single trip to memory plus the instructions, not a chain of trips.
-    constexpr int GROUP = 4;
-    for (int k = 0; k < kq; k += GROUP * TFM_STEP) {
-        f32x4 xv[GROUP][4], wv[GROUP][4];
+    // The loads of up to four chunks (a workgroup's whole share at 64 samples) are issued before the first of them is
+    // used: with one chunk in flight every round waited a full trip to memory for 0.4 us of matrix instructions.
+    constexpr int DEPTH = 4;
+    const int nchunk = krange / TFM_CHUNK;
+    for (int c0 = 0; c0 < nchunk; c0 += DEPTH) {
+        f32x4 st[DEPTH][8];
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            const int kk = k + g * TFM_STEP < kq ? k + g * TFM_STEP : k;  // (past the share: a valid address, unused)
+        for (int d = 0; d < DEPTH; ++d) {
+            const int c = c0 + d < nchunk ? c0 + d : c0;  // (past the share: a valid address, unused)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xv[g][i] = *reinterpret_cast<const f32x4*>(xp + kk + 4 * i);
-                wv[g][i] = *reinterpret_cast<const f32x4*>(wp + kk + 4 * i);
-            }
+            for (int i = 0; i < 8; ++i) st[d][i] = *reinterpret_cast<const f32x4*>(src[i] + c * TFM_CHUNK);
         }
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-            if (k + g * TFM_STEP < kq) {  // wave-uniform
+        for (int d = 0; d < DEPTH; ++d) {
+            if (c0 + d < nchunk) {  // workgroup-uniform
+                if (c0 + d > 0) __syncthreads();  // (the previous chunk's operand reads are done)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<f32x4*>(tile + (16 * wave + 2 * i + h) * TFM_LD + s_col) = st[d][i];
+                __syncthreads();
+                const float* xr = tile + l31 * TFM_LD + TFM_STEP * wave + 16 * h;
+                const float* wr = tile + (32 + l31) * TFM_LD + TFM_STEP * wave + 16 * h;
+                f32x4 xv[4], wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xv[i] = *reinterpret_cast<const f32x4*>(xr + 4 * i);
+                    wv[i] = *reinterpret_cast<const f32x4*>(wr + 4 * i);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[g][i][e], wv[g][i][e], acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i][e], wv[i][e], acc[0], 0, 0, 0);
             }
         }
     }
@@ -532,7 +568,7 @@ __global__ __launch_bounds__(256) void tail_fwd_reduce_kernel(const float* __res
 int tail_fwd_splits(int B, int Kd, int Cout) {
     const int tiles = ((B + 31) / 32) * (Cout / 32);
     int s = 1;
-    while (s * 2 * tiles <= num_cus() && Kd % (s * 2 * 4 * TFM_STEP) == 0) s *= 2;
+    while (s * 2 * tiles <= num_cus() && Kd % (s * 2 * TFM_CHUNK) == 0) s *= 2;
     return s;
 }
 
@@ -542,7 +578,7 @@ bool tail_fwd_mfma_shape(int Kd, int Cout) {
         const char* e = getenv("EEGGAN_TAIL_MFMA");
         return !(e && e[0] == '0');
     }();
-    return on && Kd % (4 * TFM_STEP) == 0 && Cout % 32 == 0;
+    return on && Kd % TFM_CHUNK == 0 && Cout % 32 == 0;
 }
 
 bool tail_mfma_shape(int Kd, int Cout) { return Kd % 32 == 0 && Cout % 32 == 0; }
