@@ -167,6 +167,11 @@ def test_losses_against_reference_fixture(dev, name):
                 assert got is None, f"{tag}.{k}: the reference leaves this gradient None"
                 continue
             assert got is not None, f"{tag}.{k}: missing gradient"
+            if f"{tag}_norm.{k}" in c and float(c[f"{tag}_norm.{k}"]) < 1e-12:
+                # a gradient that cancels exactly in the mathematics (the output layer's bias under a relativistic
+                # loss): round-off in every implementation -- 5e-17 in the reference's fp64, 0 in its fp32
+                assert float(got.norm()) < 1e-6, f"{name} {tag}.{k}: {float(got.norm()):.1e} where the gradient cancels"
+                continue
             noise = float(c[f"{tag}_noise.{k}"]) if f"{tag}_noise.{k}" in c else 0.0
             tol = max(1e-4, NOISE_FACTOR * noise, min(NOISE_FACTOR * cond[tag].get(k, 0.0), COND_CAP))
             e = rel(subsample(got), c[f"{tag}_sub.{k}"])
