@@ -378,10 +378,11 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
 // vector-ALU kernel below at 32-64 samples.  acc = mfma(a, b, acc) adds a (row i = this lane's first-operand index,
 // lane & 31) times b (column j = lane & 31) for the reduction index the lane half (lane >> 5) stands for; the result
 // has column j in lane j and row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) in register r.  The four waves of a workgroup
-// split the reduction and add their tiles through LDS.  (Measured and left on the vector ALUs: the forward pass
-// as a split-reduction GEMM -- its second launch, which adds the partial sums, makes it 16.1 against 13.7 us -- and
-// the weight gradient, whose accumulator layout stores 128-byte pieces of 256 rows where the vector kernel
-// stores 4 KB runs: 9.6 / 15.6 against 8.1 / 12.6 us at 32 / 64 samples.)
+// split the reduction and add their tiles through LDS.  (The forward pass as a split-reduction product follows
+// below: a first form that read its operands straight from global memory lost to the vector kernel stand-alone,
+// 16.1 against 13.7 us with its second launch; staged through LDS it wins inside the training step.  Measured and
+// left on the vector ALUs: the weight gradient, whose accumulator layout stores 128-byte pieces of 256 rows where
+// the vector kernel stores 4 KB runs: 9.6 / 15.6 against 8.1 / 12.6 us at 32 / 64 samples.)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // sum of the four waves' accumulator tiles (NT tiles each); every thread gets the sums of its 4 NT values back in
