@@ -371,6 +371,50 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
     }
 }
 
+// accumulator layout of the 32 x 32 matrix instructions: register r of a lane in half-wave h holds this row
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- the tail layer's weight gradient on the matrix cores, for large batches -----------------------------------------
+// gw[Cout, Kd] = in_scale * gy^T[Cout, B] x[B, Kd]: the reduction runs over the samples.  Grid (Kd / 128, Cout / 32); a
+// wave owns a 32 x 32 tile (channels x columns) and walks the samples two at a time: for a fixed sample both operands
+// are runs of 32 consecutive floats (gy[b][co0 ..], x[b][k0 ..]), read straight from global memory.  At 32-64
+// samples the vector kernel above is faster (this layout stores 128-byte pieces of 256 rows: 9.6 / 15.6 against
+// 8.1 / 12.6 us); from 128 samples on the vector ALUs' 2 B Cout Kd flops dominate (113 us at 512 samples).
+__global__ __launch_bounds__(256) void tail_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                              float* __restrict__ gw, float* __restrict__ gb, int B, int Kd,
+                                                              int Cout, float in_scale) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+    const int k0 = (blockIdx.x * 4 + wave) * 32, co0 = blockIdx.y * 32;
+    const float* gp = gy + co0 + l31;
+    const float* xp = x + k0 + l31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int U = 8;  // pairs of samples in flight
+    for (int b0 = 0; b0 < B; b0 += 2 * U) {
+        float gv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + 2 * u + h;
+            const int bc = b < B ? b : B - 1;  // (past the batch: a valid address, dropped below)
+            gv[u] = gp[(long long)bc * Cout];
+            xv[u] = xp[(long long)bc * Kd];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = b0 + 2 * u + h < B;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? gv[u] : 0.f, xv[u], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw[(long long)(co0 + acc_row(r, h)) * Kd + k0 + l31] = acc[r] * in_scale;
+    if (gb && blockIdx.x == 0 && wave == 0 && h == 0) {
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += gp[(long long)b * Cout];
+        gb[co0 + l31] = sum;
+    }
+}
+
 // ---- the tail layer's input gradient on the matrix cores -----------------------------------------------------------
 // gx[B, Kd] = gy[B, Cout] w[Cout, Kd] has a long OUTPUT axis (Kd = 8192 columns) and a short reduction (Cout): every
 // workgroup owns 32 columns and streams its 32-column strip of the weights once, in full 128-byte rows, through
@@ -383,7 +427,6 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
 // 16.1 against 13.7 us with its second launch; staged through LDS it wins inside the training step.  Measured and
 // left on the vector ALUs: the weight gradient, whose accumulator layout stores 128-byte pieces of 256 rows where
 // the vector kernel stores 4 KB runs: 9.6 / 15.6 against 8.1 / 12.6 us at 32 / 64 samples.)
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // sum of the four waves' accumulator tiles (NT tiles each); every thread gets the sums of its 4 NT values back in
 // out[]: value index v = tile * 1024 + r * 64 + lane for v = threadIdx.x + 256 i
@@ -694,6 +737,11 @@ extern "C" int eeggan_tail_wgrad(const float* x, const float* gy, float* gw, flo
     EEGGAN_REQUIRE(x && gy && gw, "tail_wgrad: null pointer");
     const int Kd = Cin * KT;
     EEGGAN_REQUIRE(Kd % 4 == 0, "tail_wgrad: Cin*KT = %d must be a multiple of 4", Kd);
+    if (B >= 128 && Kd % 128 == 0 && Cout % 32 == 0) {
+        hipLaunchKernelGGL(tail_wgrad_mfma_kernel, dim3(Kd / 128, Cout / 32), dim3(256), 0, as_stream(stream), x, gy, gw, gb, B,
+                           Kd, Cout, in_scale);
+        return check_launch("tail_wgrad");
+    }
     hipLaunchKernelGGL(tail_wgrad_kernel, dim3((Kd + 1023) / 1024, (Cout + 7) / 8), dim3(256),
                        (size_t)B * 8 * sizeof(float), as_stream(stream), x, gy, gw, gb, B, Kd, Cout, in_scale);
     return check_launch("tail_wgrad");

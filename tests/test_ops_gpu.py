@@ -391,7 +391,7 @@ def test_conv_rejects_bad_arguments(dev):
         ops.conv1d_raw(x.cpu(), torch.randn(3, 4, 3))  # no CPU path
 
 
-@pytest.mark.parametrize("B", [4, 32, 40, 64, 71, 130])
+@pytest.mark.parametrize("B", [4, 32, 40, 64, 71, 130, 131, 512])
 def test_head_tail(dev, B):
     ops = _ops()
     from eeggan_amd._lib import call
