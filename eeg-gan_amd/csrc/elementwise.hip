@@ -239,6 +239,17 @@ inline PnCfg pn_config(long long BT, bool vec) {
     return {1, 16, (unsigned)blocks(1, 16)};
 }
 
+// The wide-tile choice keeps C / 4 channels per thread: where that count has no register-resident form (256 channels at
+// a large batch: 64 per thread, 113 us for a 15 us transfer) but C / 16 has one, the 16-group shape is taken.
+inline PnCfg pn_refine(PnCfg c, int C, long long BT, bool forward) {
+    if (c.w != 4 || c.cg != 4) return c;
+    const int cpt4 = C % 4 == 0 ? C / 4 : 0, cpt16 = C % 16 == 0 ? C / 16 : 0;
+    const bool have4 = cpt4 == 16 || (forward && cpt4 == 32);
+    const bool have16 = cpt16 == 4 || cpt16 == 8 || cpt16 == 16;
+    if (!have4 && have16) return {4, 16, (unsigned)((BT / 4 + 15) / 16)};
+    return c;
+}
+
 // ---- small flat kernels ------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
@@ -418,7 +429,7 @@ static int pixelnorm_drop_fwd_impl(const ET* h, const float* drop, ET* y, float*
     EEGGAN_REQUIRE(h && y && d, "pixelnorm_drop_fwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_fwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(h) && aligned16(y) && aligned16(d);
-    PnCfg c = pn_config((long long)B * T, vec);
+    PnCfg c = pn_refine(pn_config((long long)B * T, vec), C, (long long)B * T, true);
     if (sizeof(ET) == 2) {
         EEGGAN_REQUIRE(vec, "pixelnorm_drop_fwd: bfloat16 tensors need T %% 4 == 0 and 16-byte alignment");
         if (c.w != 4) c = {4, 16, (unsigned)(((long long)B * T / 4 + 15) / 16)};
@@ -463,7 +474,7 @@ static int pixelnorm_drop_bwd_impl(const ET* gy, const ET* y, const float* drop,
     EEGGAN_REQUIRE(gy && y && d && gc, "pixelnorm_drop_bwd: null pointer");
     EEGGAN_REQUIRE(B > 0 && C > 0 && T > 0, "pixelnorm_drop_bwd: non-positive dimension");
     const bool vec = (T % 4 == 0) && aligned16(gy) && aligned16(y) && aligned16(gc);
-    PnCfg c = pn_config((long long)B * T, vec);
+    PnCfg c = pn_refine(pn_config((long long)B * T, vec), C, (long long)B * T, false);
     if (sizeof(ET) == 2) {
         EEGGAN_REQUIRE(vec, "pixelnorm_drop_bwd: bfloat16 tensors need T %% 4 == 0 and 16-byte alignment");
         if (c.w != 4) c = {4, 16, (unsigned)(((long long)B * T / 4 + 15) / 16)};

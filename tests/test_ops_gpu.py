@@ -439,7 +439,8 @@ def test_head_tail(dev, B):
     assert rel(gb, gy.double().sum(dim=(0, 2))) < TOL
 
 
-@pytest.mark.parametrize("B,C,T", [(4, 64, 1920), (3, 256, 32), (2, 9, 20), (8, 256, 1), (2, 128, 250)])
+@pytest.mark.parametrize("B,C,T", [(4, 64, 1920), (3, 256, 32), (2, 9, 20), (8, 256, 1), (2, 128, 250), (1280, 256, 32), (640, 128, 128),
+                                   (300, 192, 64)])
 def test_pixelnorm_and_masks(dev, B, C, T):
     ops = _ops()
     O = _oracle()
