@@ -199,7 +199,7 @@ template <int K, int CT, int NT, int CK, int WM, int WN, bool VEC, bool FULL, in
 __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
     static_assert(!SPLIT || (FULL && K == 3 && CK == 32 && (KS == 1 || KS == 2)), "split products: predicate-free k = 3 form");
     static_assert(!BF || (FULL && VEC && SPLIT == 1), "bf16 storage: predicate-free form with bf16 products");
-    static_assert(!RAGC || (FULL && VEC && SPLIT == 3 && !BF), "left-over input channels: predicate-free form, fp32 products");
+    static_assert(!RAGC || (FULL && VEC && SPLIT != 0 && !BF), "left-over input channels: predicate-free form, float32 storage");
     typedef typename ActT<BF>::T AT;
     typedef typename ActT<BF>::raw4 R4;
     typedef typename ActT<BF>::raw1 R1;
@@ -1077,12 +1077,20 @@ int dispatch_fwd(const ConvArgs& a, hipStream_t st) {
             return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 3, 0, false, true>(a, st)
                        : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 3, 0, false, true>(a, st);
         }
-        if (full && pieces == 1) {
+        if ((full || (full_cin && ragged_enabled())) && pieces == 1) {
             if (a.mask_y)
                 return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 1>(a, st)
                            : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 1>(a, st);
             return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 0>(a, st)
                        : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 0>(a, st);
+        }
+        // (the same with bf16 products: the left-over channels' terms stay plain fp32)
+        if (pieces == 1 && ragged_enabled() && a.Cin > 64 && a.Cin % 32 != 0 && a.Cin % 32 <= 4 && a.Cout % 64 == 0 && a.T % 32 == 0) {
+            if (a.mask_y)
+                return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 1, false, true>(a, st)
+                           : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 1, false, true>(a, st);
+            return big ? launch_fwd<K, 64, 4, 32, 1, 4, true, true, 2, 1, 0, false, true>(a, st)
+                       : launch_fwd<K, 32, 2, 32, 1, 2, true, true, 2, 1, 0, false, true>(a, st);
         }
     }
     if (big)  // (predicate-free form: eight waves, two per SIMD, splitting the reduction: +1.3 % steps/s)

@@ -74,6 +74,28 @@ def test_products_are_those_of_bf16_operands(dev, bf16_mode, shape):
     assert rel(gb, gy.double().sum(dim=(0, 2))) < 1e-5  # the bias gradient is summed in fp32 from the fp32 values
 
 
+@pytest.mark.parametrize("shape", [(16, 257, 256, 32), (600, 257, 256, 32), (16, 256, 257, 32), (600, 256, 257, 32)])
+def test_ragged_channel_layers_in_bf16_mode(dev, bf16_mode, shape):
+    """The 256 + 1 channel layer and its input gradient in the bf16 mode: the 32 n channels' products are those of
+    bf16 operands, the left-over channel's terms are added in float32 (unrounded)."""
+    from eeggan_amd import ops
+    B, Cin, Cout, T = shape
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, T, generator=gen)
+    w = torch.randn(Cout, Cin, 3, generator=gen)
+    b = torch.randn(Cout, generator=gen)
+    s = 0.07
+    y = ops.conv1d_raw(x.to(dev), w.to(dev), b.to(dev), None, in_scale=s)
+    main = Cin - Cin % 32
+    ref = F.conv1d(_bf(x[:, :main]), _bf(w[:, :main] * s), b.double(), padding=1)
+    if main < Cin:
+        ref = ref + F.conv1d(x[:, main:].double(), (w[:, main:] * s).double(), None, padding=1)
+    sel = sorted({0, 1, B // 2, B - 1})
+    assert rel(y[sel], ref[sel]) < 2e-6, rel(y[sel], ref[sel])
+    exact = F.conv1d(x.double(), (w * s).double(), b.double(), padding=1)
+    assert 1e-4 < rel(y[sel], exact[sel]) < 1e-2  # (the matrix-core kernel with bf16 products ran, not the fp32 generic one)
+
+
 def test_default_mode_is_untouched(dev):
     from eeggan_amd import ops
     assert ops.get_precision() == "fp32"
