@@ -1175,9 +1175,13 @@ unsigned long long* g_wgrad_trace = nullptr;  // (trace builds: where the next w
 // W4 (split fp32 form): four waves per workgroup, each taking BOTH subtiles of a pair, and ONE LDS buffer (43 KB), so
 // that two workgroups share a CU.  Per SIMD that is still two waves, but of two workgroups that do not wait at each
 // other's barriers: while one waits for its loads, the other multiplies.
-template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false>
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false, bool RAGX = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, const int region) {
     static_assert(!W4 || (SPLIT != 0 && !XBF && !GBF), "four-wave form: products on the bf16 pipe, float32 tensors");
+    // RAGX: Cin is not a multiple of 64 (256 + 1 behind MinibatchStddev).  The last region's missing x rows are read
+    // from the last channel again (valid addresses); what they accumulate is never stored (the slab stores are guarded
+    // by ci < Cin).  A form of its own: the other layers' loop keeps its immediate row offsets.
+    static_assert(!RAGX || (FULL && W4), "ragged input channels: a variant of the four-wave predicate-free form");
     static_assert(!SPLIT || (FULL && K == 3), "split products: predicate-free k = 3 form only");
     static_assert(!(FULL && (XBF || GBF)) || (SPLIT == 1 && XBF && GBF), "bf16 storage, predicate-free form: bf16 products, both sides");
     typedef typename ActT<XBF>::T XT;
@@ -1426,7 +1430,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
             for (int i = 0; i < NI; ++i) {
                 const long long o = (long long)(RSTEP * i) * a.T;
                 gv[i] = ld_raw4(gp + o);
-                xv[i] = ld_raw4(xp + o);
+                if constexpr (RAGX) {
+                    const int row = ci0 + r0 + RSTEP * i < a.Cin ? ci0 + r0 + RSTEP * i : a.Cin - 1;
+                    xv[i] = ld_raw4(X0 + ((long long)b * a.Cin + row) * a.T + t0 + 4 * q);
+                } else {
+                    xv[i] = ld_raw4(xp + o);
+                }
                 if (a.mask_y) {  // wave-uniform
                     mv[i] = ld_raw4(mp + o);
                     md[i] = dp[a.mask_drop ? RSTEP * i : 0];
@@ -1436,7 +1445,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int split, 
                 const int hb = hn ? bb[1] : bb[0], ht0 = hn ? tt[1] : tt[0];
                 const int t = ht0 + (hs ? 32 : -1);
                 hok = (hn ? vv[1] : vv[0]) && t >= 0 && t < a.T && hr < 64;
-                hv = ld_raw1(X0 + (hok ? ((long long)hb * a.Cin + ci0 + hr) * a.T + t : 0));
+                const int hrow = (RAGX && ci0 + hr >= a.Cin) ? a.Cin - 1 : ci0 + hr;
+                hv = ld_raw1(X0 + (hok ? ((long long)hb * a.Cin + hrow) * a.T + t : 0));
             }
         };
         auto commit = [&](float* Gs, float* Xs) {
@@ -1738,7 +1748,7 @@ struct WgradPack {
 };
 
 // (the bfloat16-native form asks for registers that let two workgroups of eight waves share a CU: four waves per SIMD)
-template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false>
+template <int K, bool FULL, int SPLIT = 0, bool XBF = false, bool GBF = false, bool W4 = false, bool RAGX = false>
 __global__ __launch_bounds__((SPLIT && !W4) ? 512 : 256, (FULL && SPLIT == 1 && XBF && GBF) ? 4 : (W4 ? WGRAD_W4_PER_CU : 1))
 void conv_wgrad_multi_kernel(WgradPack pk) {
     const int blk = blockIdx.x;
@@ -1747,7 +1757,7 @@ void conv_wgrad_multi_kernel(WgradPack pk) {
     const WgradArgs a = pk.j[k];
     const int local = blk - pk.first[k];
     const int region = local / a.nsplit;
-    wgrad_body<K, FULL, SPLIT, XBF, GBF, W4>(a, local - region * a.nsplit, region);
+    wgrad_body<K, FULL, SPLIT, XBF, GBF, W4, RAGX>(a, local - region * a.nsplit, region);
 }
 
 // Sum of the partial slabs: 64 consecutive elements x 4 split groups per workgroup, eight
@@ -2198,6 +2208,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     };
     auto variant = [&](const eeggan_wgrad_job& j) {
         if (thin(j)) return -1;
+        // (12: the four-wave split form with ragged input channels -- float32 tensors, fp32 products)
+        if (j.K == 3 && j.Cin % 64 != 0 && j.Cin > 64 && j.Cout % 64 == 0 && j.T % 32 == 0 && !j.x_bf16 && !j.gy_bf16 &&
+            product_pieces() == 3 && wgrad_four_wave() && ragged_enabled())
+            return 12;
         const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
         return (j.K == 3 ? (full ? 0 : 1) : 2) * 4 + (j.x_bf16 ? 2 : 0) + (j.gy_bf16 ? 1 : 0);
     };
@@ -2260,11 +2274,11 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
         rb.slabs = a.ws_b; rb.out = nullptr; rb.elems = j.want_bias ? j.Cout : 0; rb.nsplit = (int)nsplit;
         rb.scale = 1.f; rb.beta = 0.f; rb.reserved = 0;
     }
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 13; ++v) {
         int idx[WG_MAXJ];
         int n = 0;
         // (two workgroups per CU: the bfloat16-native form, and the four-wave form of the split fp32 products)
-        const bool four_wave = v == 0 && product_pieces() != 0 && wgrad_four_wave();
+        const bool four_wave = (v == 0 && product_pieces() != 0 && wgrad_four_wave()) || v == 12;
         // (the generic and the 1x1 forms: four waves and one 43 KB buffer as well)
         const int per_cu = four_wave ? WGRAD_W4_PER_CU : ((v == 3 || v / 4 >= 1) ? 2 : 1);
         const int cus = per_cu * num_cus();
@@ -2322,7 +2336,10 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
                 rb.scale = 1.f; rb.beta = 0.f; rb.reserved = 0;
             }
             for (int k = n; k <= WG_MAXJ; ++k) pk.first[k] = first;
-            if (v / 4 == 0) {
+            if (v == 12) {
+                hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3, false, false, true, true>), dim3(first), dim3(256), lds1,
+                                   st, pk);
+            } else if (v / 4 == 0) {
                 // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once per device)
                 static std::atomic<bool> ready_dev[MAX_DEVICES];
                 std::atomic<bool>& ready = ready_dev[current_device()];

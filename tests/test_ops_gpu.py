@@ -131,6 +131,18 @@ def test_conv_ragged_channels(dev, B, Cin, Cout, T):
     y = ops.conv1d_raw(xd, wd, None, dd, in_scale=scale, mask_y=myd, mask_drop=mdd, mask_slope=0.2, act=3, act_param=0.2,
                        act_aux=auxd)
     assert rel(y[sel], refm) < TOL
+    # weight gradient (input channels that are not a multiple of 64 take the split kernel with clamped rows), plain and
+    # with the fused mask on the output gradient
+    gy = torch.randn(B, Cout, T, generator=g)
+    x64, w64 = x.double(), w.double().requires_grad_(True)
+    lin = F.conv1d(x64 * scale, w64, None, padding=1)
+    (gw_ref,) = torch.autograd.grad(lin, w64, gy.double(), retain_graph=True)
+    gw, gb = ops.conv1d_wgrad_raw(xd, gy.to(dev), 3, in_scale=scale)
+    assert rel(gw, gw_ref) < TOL and rel(gb, gy.double().sum(dim=(0, 2))) < TOL
+    mask = torch.where(aux > 0, 1.0, 0.2).double() * drop.double()[:, :, None]
+    (gwm_ref,) = torch.autograd.grad(lin, w64, gy.double() * mask)
+    gwm, gbm = ops.conv1d_wgrad_raw(xd, gy.to(dev), 3, in_scale=scale, mask_y=auxd, mask_drop=dd, mask_slope=0.2)
+    assert rel(gwm, gwm_ref) < TOL and rel(gbm, (gy.double() * mask).sum(dim=(0, 2))) < TOL
     # the left-over channels alone must be right too: weights that are zero everywhere else
     if Cin % 32:
         w2 = w.clone()
