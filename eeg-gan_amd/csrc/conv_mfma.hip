@@ -2208,9 +2208,9 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
     };
     auto variant = [&](const eeggan_wgrad_job& j) {
         if (thin(j)) return -1;
-        // (12: the four-wave split form with ragged input channels -- float32 tensors, fp32 products)
+        // (12: the four-wave split form with ragged input channels -- float32 tensors, fp32 or bf16 products)
         if (j.K == 3 && j.Cin % 64 != 0 && j.Cin > 64 && j.Cout % 64 == 0 && j.T % 32 == 0 && !j.x_bf16 && !j.gy_bf16 &&
-            product_pieces() == 3 && wgrad_four_wave() && ragged_enabled())
+            product_pieces() != 0 && wgrad_four_wave() && ragged_enabled())
             return 12;
         const bool full = j.Cin % 64 == 0 && j.Cout % 64 == 0 && j.T % 32 == 0;
         return (j.K == 3 ? (full ? 0 : 1) : 2) * 4 + (j.x_bf16 ? 2 : 0) + (j.gy_bf16 ? 1 : 0);
@@ -2337,8 +2337,12 @@ extern "C" int eeggan_conv1d_wgrad_partial_multi(const eeggan_wgrad_job* jobs, i
             }
             for (int k = n; k <= WG_MAXJ; ++k) pk.first[k] = first;
             if (v == 12) {
-                hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3, false, false, true, true>), dim3(first), dim3(256), lds1,
-                                   st, pk);
+                if (product_pieces() == 3)
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 3, false, false, true, true>), dim3(first), dim3(256),
+                                       lds1, st, pk);
+                else
+                    hipLaunchKernelGGL((conv_wgrad_multi_kernel<3, true, 1, false, false, true, true>), dim3(first), dim3(256),
+                                       lds1, st, pk);
             } else if (v / 4 == 0) {
                 // two LDS buffers = 86 KB: opt in to > 64 KiB of dynamic LDS (once per device)
                 static std::atomic<bool> ready_dev[MAX_DEVICES];

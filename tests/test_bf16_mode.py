@@ -94,6 +94,14 @@ def test_ragged_channel_layers_in_bf16_mode(dev, bf16_mode, shape):
     assert rel(y[sel], ref[sel]) < 2e-6, rel(y[sel], ref[sel])
     exact = F.conv1d(x.double(), (w * s).double(), b.double(), padding=1)
     assert 1e-4 < rel(y[sel], exact[sel]) < 1e-2  # (the matrix-core kernel with bf16 products ran, not the fp32 generic one)
+    if Cin % 64:  # the weight gradient of such a layer: both operands rounded, the scale applied to the sum
+        gy = torch.randn(B, Cout, T, generator=gen)
+        # (through the grouped entry point, the one the training step submits its layers to)
+        gw, gb = ops.conv1d_wgrad_group_raw([dict(x=x.to(dev), gy=gy.to(dev), K=3, in_scale=s)])[0]
+        xp = F.pad(_bf(x), (1, 1))
+        ref = s * torch.stack([torch.einsum("bot,bit->oi", _bf(gy), xp[:, :, j:j + T]) for j in range(3)], dim=2)
+        assert rel(gw, ref) < 2e-6, rel(gw, ref)
+        assert rel(gb, gy.double().sum(dim=(0, 2))) < 1e-5
 
 
 def test_default_mode_is_untouched(dev):

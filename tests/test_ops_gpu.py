@@ -143,6 +143,12 @@ def test_conv_ragged_channels(dev, B, Cin, Cout, T):
     (gwm_ref,) = torch.autograd.grad(lin, w64, gy.double() * mask)
     gwm, gbm = ops.conv1d_wgrad_raw(xd, gy.to(dev), 3, in_scale=scale, mask_y=auxd, mask_drop=dd, mask_slope=0.2)
     assert rel(gwm, gwm_ref) < TOL and rel(gbm, (gy.double() * mask).sum(dim=(0, 2))) < TOL
+    # (and through the grouped entry point, the one the training step submits its layers to)
+    (gw2, gb2), (gwm2, gbm2) = ops.conv1d_wgrad_group_raw([
+        dict(x=xd, gy=gy.to(dev), K=3, in_scale=scale),
+        dict(x=xd, gy=gy.to(dev), K=3, in_scale=scale, mask_y=auxd, mask_drop=dd, mask_slope=0.2)])
+    assert rel(gw2, gw_ref) < TOL and rel(gwm2, gwm_ref) < TOL
+    assert rel(gb2, gy.double().sum(dim=(0, 2))) < TOL and rel(gbm2, (gy.double() * mask).sum(dim=(0, 2))) < TOL
     # the left-over channels alone must be right too: weights that are zero everywhere else
     if Cin % 32:
         w2 = w.clone()
