@@ -88,6 +88,16 @@ def _batch_coupled(dis) -> bool:
     return any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in dis.modules())
 
 
+def _no_dropped_classes(dis):
+    """The critic losses hand the critic signals only (``{'x': ...}`` for fakes, interpolates and the stacked
+    pass), so a critic built with ``num_classes`` would silently lose its projection term.  The reference's losses
+    cannot train such a critic either (they hand its forward whole dicts, losses.py:76-79, 108-113 against
+    network.py:528); refuse instead of training it as an unconditional one."""
+    if getattr(dis, "class_emb", None) is not None:
+        raise NotImplementedError("discriminator_loss runs the critic without classes: a critic built with "
+                                  "num_classes != 0 would be trained without its projection term")
+
+
 class PartsUnavailable(ValueError):
     """The critic loss was asked for one of its independent parts but does not split for this configuration."""
 
@@ -147,14 +157,15 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
     if loss_type != "wgan_gp":
         return _other_discriminator_loss(dis, gen, real, z, loss_type, iwass_drift_epsilon, grad_lambda, iwass_target,
                                          mixing, stack_real_fake, fake, part, zero_grad)
-    if grad_lambda == 0:
-        raise NotImplementedError("wgan_gp with grad_lambda == 0 (no penalty) is not supported")
+    _no_dropped_classes(dis)
     layers.drop_pool_reset()
     if zero_grad:
         dis.zero_grad()
     real_x = real["x"] if isinstance(real, dict) else real
     if stack_real_fake is None:
         stack_real_fake = layers.get_drop_mode() == "device" and not _batch_coupled(dis)
+    if part is not None and grad_lambda == 0:
+        raise PartsUnavailable("without a penalty (grad_lambda == 0) the critic loss is one term")
     if part is not None and not stack_real_fake:
         if _batch_coupled(dis):
             raise PartsUnavailable("a critic with batch norm layers sees reals, fakes and interpolates as batches of "
@@ -185,7 +196,8 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         if part in (None, "scores"):
             with layers.batch_segments(2):
                 scores, _, _ = dis({"x": _stacked(real_x, fake_x)})
-            if part == "scores":
+            if part == "scores" or grad_lambda == 0:
+                # (the reference skips the interpolates' pass without a penalty, losses.py:106)
                 nothing = get_zero(n).view(n, 1)  # no penalty: lambda = 0 on an all-zero "gradient"
                 return ops.wgan_gp_d_loss_stacked(scores, nothing, iwass_drift_epsilon, 0.0, iwass_target)
         alpha = get_mixing_factor(n) if mixing is None else mixing
@@ -204,6 +216,9 @@ def discriminator_loss(dis: torch.nn.Module, gen: torch.nn.Module, real, z, loss
         else:
             fake_x = fake
         d_fake, _, _ = dis({"x": fake_x})
+        if grad_lambda == 0:
+            n = real_x.size(0)
+            return ops.wgan_gp_d_loss(d_real, d_fake, get_zero(n).view(n, 1), iwass_drift_epsilon, 0.0, iwass_target)
     alpha = get_mixing_factor(real_x.size(0)) if mixing is None else mixing
     x_hat = {"x": ops.mix_batch_raw(real_x.detach(), fake_x.detach(), alpha).requires_grad_(True)}
     pred_hat, _, _ = dis(x_hat)
@@ -220,6 +235,7 @@ def _other_discriminator_loss(dis, gen, real, z, loss_type, drift, grad_lambda, 
     is scaled by a function of the scores) and neither does a loss without penalty."""
     if part in ("real", "fake") or (part is not None and (loss_type == "wgan_theirs" or grad_lambda == 0)):
         raise PartsUnavailable(f"loss_type={loss_type!r}, grad_lambda={grad_lambda}: part={part!r} is not available")
+    _no_dropped_classes(dis)
     layers.drop_pool_reset()
     if zero_grad:
         dis.zero_grad()

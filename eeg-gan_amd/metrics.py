@@ -40,19 +40,18 @@ class SlicedWDistance(Plugin):
                  patch_size: int = 49, max_items: int = 1024, number_of_projections: int = 512,
                  dir_repeats: int = 4, dirs_per_repeat: int = 128):
         super().__init__([(1, "epoch")])
-        self.output_snapshot_ticks = output_snapshot_ticks
-        self.progression_scale = progression_scale
-        self.patches_per_item = patches_per_item
-        self.patch_size = patch_size
-        self.max_items = max_items
-        self.number_of_projections = number_of_projections
-        self.dir_repeats = dir_repeats
-        self.dirs_per_repeat = dirs_per_repeat
+        # when: every ``output_snapshot_ticks`` epochs, on at most ``max_items`` signals per set
+        self.output_snapshot_ticks, self.max_items = output_snapshot_ticks, max_items
+        # patches: ``patches_per_item`` windows of ``patch_size`` samples, one set per pyramid level
+        self.progression_scale, self.patches_per_item, self.patch_size = progression_scale, patches_per_item, patch_size
+        # directions (``number_of_projections`` is carried, and unused, as in the reference plugins.py:371)
+        self.number_of_projections, self.dir_repeats, self.dirs_per_repeat = (number_of_projections, dir_repeats,
+                                                                              dirs_per_repeat)
 
     def register(self, trainer):
+        trainer.stats["swd"] = dict(log_name="swd", log_epoch_fields=["{val:.2f}", "{epoch:.2f}"],
+                                    val=float("nan"), epoch=0)
         self.trainer = trainer
-        self.trainer.stats["swd"] = {"log_name": "swd", "log_epoch_fields": ["{val:.2f}", "{epoch:.2f}"],
-                                     "val": float("nan"), "epoch": 0}
 
     # ---- device pieces ---------------------------------------------------------------------------------
     def _sorted_projections(self, desc: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
@@ -135,32 +134,31 @@ class SlicedWDistance(Plugin):
             swd.append(self.sliced_wasserstein(d1, d2))
         return swd
 
+    def _gather(self, next_batch) -> torch.Tensor:
+        """Batches from ``next_batch()`` until ``max_items`` signals are there; one batch is enough when the
+        signals are shorter than a patch (nothing can be measured on them: reference plugins.py:409-410)."""
+        batches, have = [], 0
+        while have < self.max_items:
+            batches.append(next_batch())
+            if batches[-1].size(2) < self.patch_size:
+                break
+            have += batches[-1].size(0)
+        return torch.cat(batches, dim=0)
+
     def epoch(self, epoch_index):
-        if epoch_index % self.output_snapshot_ticks != 0:
+        """Every ``output_snapshot_ticks`` epochs: generated signals against reals, one distance per level and
+        their mean last, into ``stats['swd']`` (reference plugins.py:397-424; both sets stay on the device)."""
+        if epoch_index % self.output_snapshot_ticks:
             return
         gc.collect()
-        all_fakes, all_reals = [], []
+        tr = self.trainer
         with torch.no_grad():
-            remaining = self.max_items
-            while remaining > 0:
-                z = cudize(next(self.trainer.random_latents_generator))
-                all_fakes.append(self.trainer.generator(z)[0]["x"].detach())
-                if all_fakes[-1].size(2) < self.patch_size:
-                    break
-                remaining -= all_fakes[-1].size(0)
-            all_fakes = torch.cat(all_fakes, dim=0)
-            remaining = self.max_items
-            while remaining > 0:
-                all_reals.append(cudize(next(self.trainer.dataiter))["x"])
-                if all_reals[-1].size(2) < self.patch_size:
-                    break
-                remaining -= all_reals[-1].size(0)
-            all_reals = torch.cat(all_reals, dim=0)
-        swd = self.get_descriptors(all_fakes, all_reals)
-        if len(swd) > 0:
-            swd.append(np.array(swd).mean())
-        self.trainer.stats["swd"]["val"] = swd
-        self.trainer.stats["swd"]["epoch"] = epoch_index
+            fakes = self._gather(lambda: tr.generator(cudize(next(tr.random_latents_generator)))[0]["x"].detach())
+            reals = self._gather(lambda: cudize(next(tr.dataiter))["x"])
+        per_level = self.get_descriptors(fakes, reals)
+        if per_level:
+            per_level.append(np.array(per_level).mean())
+        tr.stats["swd"].update(val=per_level, epoch=epoch_index)
 
 
 class FidCalculator(Plugin):

@@ -6,6 +6,8 @@ protocol (torch_utils.py:4-12).  Monitoring / checkpoint / metric plugins are ou
 """
 from __future__ import annotations
 
+import bisect
+
 
 class Plugin(object):
     def __init__(self, interval=None):
@@ -18,6 +20,10 @@ class Plugin(object):
 
 
 class DepthManager(Plugin):
+    """Progressive-growing schedule (reference plugins.py:28-119).  The schedule is a sorted list of image counts
+    (``alpha_map``: end of a stable phase, end of the following fade-in, ...), looked up by bisection; a stage's
+    settings (minibatch, learning rate, tick length) come from ``stage_settings``; ``iteration`` applies what changed
+    to the trainer it was registered with."""
     minibatch_override = {0: 256, 1: 256, 2: 128, 3: 128, 4: 48, 5: 32, 6: 32, 7: 32, 8: 16, 9: 16, 10: 8, 11: 8}
     tick_kimg_override = {4: 4, 5: 4, 6: 4, 7: 3, 8: 3, 9: 2, 10: 2, 11: 1}
     training_kimg_override = {1: 200, 2: 200, 3: 200, 4: 200}
@@ -27,28 +33,25 @@ class DepthManager(Plugin):
                  reset_optimizer: bool = True, disable_progression=False, minibatch_default=256, depth_offset=0,
                  lod_training_kimg=400, lod_transition_kimg=400):
         super().__init__([(1, "iteration")])
-        self.reset_optimizer = reset_optimizer
-        self.minibatch_default = minibatch_default
-        self.tick_kimg_default = tick_kimg_default
-        self.create_dataloader_fun = create_dataloader_fun
-        self.create_rlg = create_rlg
-        self.trainer = None
-        self.depth = -1
-        self.alpha = -1
-        self.get_optimizer = get_optimizer
-        self.disable_progression = disable_progression
-        self.depth_offset = depth_offset
-        self.max_depth = max_depth
-        self.default_lr = default_lr
+        # what a stage change builds
+        self.create_dataloader_fun, self.create_rlg, self.get_optimizer = create_dataloader_fun, create_rlg, get_optimizer
+        # the schedule
+        self.depth_offset, self.max_depth, self.disable_progression = depth_offset, max_depth, disable_progression
         self.alpha_map = self.pre_compute_alpha_map(depth_offset, max_depth, lod_training_kimg,
                                                     self.training_kimg_override, lod_transition_kimg,
                                                     self.transition_kimg_override)
+        # per-stage settings
+        self.minibatch_default, self.tick_kimg_default, self.default_lr = minibatch_default, tick_kimg_default, default_lr
+        self.reset_optimizer = reset_optimizer
+        # state: nothing applied yet, so the first ``iteration`` installs both depth and alpha
+        self.trainer, self.depth, self.alpha = None, -1, -1
 
     def register(self, trainer):
+        resuming = trainer.optimizer_d is not None  # optimizers handed in: keep them for the first stage
+        trainer.stats.update(minibatch_size=self.minibatch_default,
+                             alpha=dict(log_name="alpha", log_epoch_fields=["{val:.2f}"], val=self.alpha))
         self.trainer = trainer
-        trainer.stats["minibatch_size"] = self.minibatch_default
-        trainer.stats["alpha"] = {"log_name": "alpha", "log_epoch_fields": ["{val:.2f}"], "val": self.alpha}
-        self.iteration(is_resuming=trainer.optimizer_d is not None)
+        self.iteration(is_resuming=resuming)
 
     @staticmethod
     def pre_compute_alpha_map(start_depth, max_depth, lod_training_kimg, lod_training_kimg_overrides,
@@ -64,48 +67,51 @@ class DepthManager(Plugin):
         return boundaries
 
     def calc_progress(self, cur_nimg=None):
+        """(depth, alpha) after ``cur_nimg`` images.  ``alpha_map[2s]`` ends stage s's stable phase and
+        ``alpha_map[2s + 1]`` the fade-in of stage s + 1; an image count exactly on a boundary still belongs to
+        the phase that ends there, with alpha 1."""
+        if self.disable_progression:
+            return self.max_depth, 1.0
         if cur_nimg is None:
             cur_nimg = self.trainer.cur_nimg
-        depth, alpha = self.depth_offset, 1.0
-        for i, point in enumerate(self.alpha_map):
-            if cur_nimg == point:
-                break
-            fading_segment = i % 2 == 1
-            if cur_nimg > point:
-                if not fading_segment:
-                    depth += 1
-                continue
-            if fading_segment:
-                start = self.alpha_map[i - 1]
-                alpha = (cur_nimg - start) / (point - start)
-            break
-        depth = min(self.max_depth, depth)
-        if self.disable_progression:
-            depth, alpha = self.max_depth, 1.0
-        return depth, alpha
+        phase = bisect.bisect_left(self.alpha_map, cur_nimg)  # first boundary not yet passed
+        depth, alpha = self.depth_offset + (phase + 1) // 2, 1.0
+        if phase % 2 == 1 and phase < len(self.alpha_map) and self.alpha_map[phase] != cur_nimg:
+            fade_start, fade_end = self.alpha_map[phase - 1], self.alpha_map[phase]
+            alpha = (cur_nimg - fade_start) / (fade_end - fade_start)
+        return min(self.max_depth, depth), alpha
+
+    def stage_settings(self, depth):
+        """(minibatch, learning rate, images per tick) of a stage: the learning rate scales with
+        ``minibatch_default / minibatch`` (reference plugins.py:105-113)."""
+        stage = depth - self.depth_offset
+        minibatch = self.minibatch_override.get(stage, self.minibatch_default)
+        return (minibatch, self.minibatch_default * self.default_lr / minibatch,
+                int(self.tick_kimg_override.get(stage, self.tick_kimg_default) * 1000))
+
+    def _enter_stage(self, depth, keep_optimizers):
+        tr = self.trainer
+        minibatch, lr, tick_nimg = self.stage_settings(depth)
+        for holder, attr in ((tr.discriminator, "depth"), (tr.generator, "depth"), (tr.dataset, "model_depth"),
+                             (self, "depth")):
+            setattr(holder, attr, depth)
+        if self.reset_optimizer and not keep_optimizers:
+            tr.optimizer_g, tr.optimizer_d, tr.lr_scheduler_g, tr.lr_scheduler_d = self.get_optimizer(lr)
+        self.data_loader = self.create_dataloader_fun(minibatch)
+        tr.dataiter = iter(self.data_loader)
+        tr.random_latents_generator = self.create_rlg(minibatch)
+        tr.tick_duration_nimg = tick_nimg
+        tr.stats["minibatch_size"] = minibatch
 
     def iteration(self, is_resuming=False, *args):
         depth, alpha = self.calc_progress()
-        tr = self.trainer
-        dataset = tr.dataset
-        if depth != self.depth:
-            tr.discriminator.depth = tr.generator.depth = dataset.model_depth = depth
-            self.depth = depth
-            stage = depth - self.depth_offset
-            minibatch_size = self.minibatch_override.get(stage, self.minibatch_default)
-            if self.reset_optimizer and not is_resuming:
-                tr.optimizer_g, tr.optimizer_d, tr.lr_scheduler_g, tr.lr_scheduler_d = self.get_optimizer(
-                    self.minibatch_default * self.default_lr / minibatch_size)
-            self.data_loader = self.create_dataloader_fun(minibatch_size)
-            tr.dataiter = iter(self.data_loader)
-            tr.random_latents_generator = self.create_rlg(minibatch_size)
-            tr.tick_duration_nimg = int(self.tick_kimg_override.get(stage, self.tick_kimg_default) * 1000)
-            tr.stats["minibatch_size"] = minibatch_size
-        if alpha != self.alpha:
-            tr.discriminator.alpha = tr.generator.alpha = dataset.alpha = alpha
-            self.alpha = alpha
-        tr.stats["depth"] = depth
-        tr.stats["alpha"]["val"] = alpha
+        if self.depth != depth:
+            self._enter_stage(depth, keep_optimizers=is_resuming)
+        if self.alpha != alpha:
+            tr = self.trainer
+            tr.discriminator.alpha = tr.generator.alpha = tr.dataset.alpha = self.alpha = alpha
+        self.trainer.stats["depth"] = depth
+        self.trainer.stats["alpha"]["val"] = alpha
 
 
 class OutputGenerator(Plugin):

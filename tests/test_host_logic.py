@@ -77,6 +77,19 @@ def test_depth_manager_schedule():
     assert tr.discriminator.depth == 7 and tr.discriminator.alpha == 0.5 and tr.dataset.model_depth == 7
     assert batches[-1] == 32 and abs(lrs[-1] - 0.008) < 1e-12 and tr.tick_duration_nimg == 3000
     assert tr.optimizer_g == "g" and tr.stats["minibatch_size"] == 32
+    # every image count of a schedule with zero-length phases (repeated boundaries) against the reference's loop
+    for amap in ([0, 5, 5, 9], [3, 3, 8, 8], [2, 6, 6, 6, 6, 11]):
+        dm.alpha_map = amap
+        for nimg in range(0, 14):
+            assert dm.calc_progress(nimg) == O.calc_progress(nimg, amap, 7), (amap, nimg)
+    # resuming keeps the optimizers that were handed in; a disabled progression sits at the last stage
+    tr2 = _Trainer()
+    tr2.optimizer_d = tr2.optimizer_g = "kept"
+    dm2 = DepthManager(lambda mb: [None], lambda mb: iter(()), 7, 5.0, lambda lr: 1 / 0, 0.001,
+                       disable_progression=True)
+    dm2.register(tr2)
+    assert tr2.optimizer_d == "kept" and (tr2.generator.depth, tr2.generator.alpha) == (7, 1.0)
+    assert tr2.stats["depth"] == 7 and tr2.stats["alpha"]["val"] == 1.0 and dm2.stage_settings(4)[0] == 48
 
 
 def test_resample_tables_match_interpolate_then_pool():

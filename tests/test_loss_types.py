@@ -3,7 +3,7 @@ one-sided gradient penalty and the running average of the generator's weights (p
 
 Fixture ``loss_types.npz`` (``tools/make_golden.py``): the reference's critic and generator losses and all
 parameter gradients at depth 1, 8 samples, in fp64 and fp32, per loss type; ``wgan_theirs`` once with its penalty
-gain above zero and once at zero."""
+gain above zero and once at zero; ``wgan_gp`` also with ``grad_lambda = 0`` (no penalty, losses.py:106)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ from helpers import load_fixture, oracle_params, rel, subsample
 
 NOISE_FACTOR = 2.0
 TYPES = {"hinge": "hinge", "rsgan": "rsgan", "rasgan": "rasgan", "rahinge": "rahinge", "wgan_gp": "wgan_gp",
-         "wgan_theirs_on": "wgan_theirs", "wgan_theirs_off": "wgan_theirs"}
+         "wgan_theirs_on": "wgan_theirs", "wgan_theirs_off": "wgan_theirs", "wgan_gp_nopenalty": "wgan_gp"}
 
 
 def _case(fx, name):
@@ -35,7 +35,8 @@ def test_oracle_matches_reference(name):
     cfg = O.NetConfig()
     np.random.seed(seed + 1)
     src = O.DropSource("numpy")
-    loss, _ = O.d_loss_any(TYPES[name], dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+    loss, _ = O.d_loss_any(TYPES[name], dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src,
+                           grad_lambda=float(c["grad_lambda"]))
     assert abs(float(loss) - float(c["d_loss"])) < 1e-9 * max(1.0, abs(float(c["d_loss"])))
     for k, gr in zip(dp.keys(), torch.autograd.grad(loss, list(dp.values()), allow_unused=True)):
         if f"d_none.{k}" in c:
@@ -138,8 +139,8 @@ def test_losses_against_reference_fixture(dev, name):
 
     def evaluate(jitter=lambda t: t):
         np.random.seed(seed + 1)
-        d_loss = losses.discriminator_loss(d, g, {"x": jitter(real)}, {"z": jitter(z)}, TYPES[name], 1e-3, 10.0, 1.0,
-                                           mixing=mix)
+        d_loss = losses.discriminator_loss(d, g, {"x": jitter(real)}, {"z": jitter(z)}, TYPES[name], 1e-3,
+                                           float(c["grad_lambda"]), 1.0, mixing=mix)
         d_loss.backward()
         d_grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in d.named_parameters()}
         np.random.seed(seed + 2)

@@ -514,7 +514,8 @@ def loss_types_fixture(out_dir):
     depth, alpha, batch = 1, 1.0, 8
     T = cfgmod.seq_len(depth)
     fx = {"depth": np.array(depth), "alpha": np.array(alpha), "model_seed": np.array(cfgmod.RANDOM_SEED)}
-    cases = [("hinge", 201), ("rsgan", 202), ("rasgan", 203), ("rahinge", 204), ("wgan_gp", 205)]
+    cases = [("hinge", 201, 10.0), ("rsgan", 202, 10.0), ("rasgan", 203, 10.0), ("rahinge", 204, 10.0),
+             ("wgan_gp", 205, 10.0)]
     found = {}
     for seed in range(206, 260):  # wgan_theirs: one seed for each sign of mean D(real) - mean D(fake)
         cases_try = ("wgan_theirs", seed)
@@ -533,9 +534,11 @@ def loss_types_fixture(out_dir):
             found[key] = cases_try
         if len(found) == 2:
             break
-    cases += [("wgan_theirs", found["on"][1]), ("wgan_theirs", found["off"][1])]
+    cases += [("wgan_theirs", found["on"][1], 10.0), ("wgan_theirs", found["off"][1], 10.0)]
+    # wgan_gp without its penalty (grad_lambda = 0: the reference then skips the interpolates' pass, losses.py:106)
+    cases += [("wgan_gp", 261, 0.0)]
     names = []
-    for loss_type, seed in cases:
+    for loss_type, seed, grad_lambda in cases:
         rng = np.random.default_rng(seed)
         real32 = torch.from_numpy(O.synthetic_eeg(batch, cfgmod.NUM_CHANNELS, T, rng))
         torch.manual_seed(seed)
@@ -555,7 +558,7 @@ def loss_types_fixture(out_dir):
             # (the reference caches float32 targets for its BCE terms, losses.py:21-32; a run is in one dtype throughout)
             ref_losses.one, ref_losses.zero = torch.ones(batch).to(dtype), torch.zeros(batch).to(dtype)
             try:
-                d_loss = ref_losses.discriminator_loss(da, ga, {"x": real}, {"z": z}, loss_type, 1e-3, 10.0, 1.0)
+                d_loss = ref_losses.discriminator_loss(da, ga, {"x": real}, {"z": z}, loss_type, 1e-3, grad_lambda, 1.0)
             finally:
                 ref_losses.get_mixing_factor = orig
             d_loss.backward()
@@ -576,7 +579,8 @@ def loss_types_fixture(out_dir):
         cfg = O.NetConfig()
         np.random.seed(seed + 1)
         src = O.DropSource("numpy")
-        ol, info = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
+        ol, info = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src,
+                                   grad_lambda=grad_lambda)
         og = dict(zip(dp.keys(), torch.autograd.grad(ol, list(dp.values()), allow_unused=True)))
         assert rel(ol, d_loss) < 1e-9, (loss_type, "d_loss", rel(ol, d_loss))
         for k, v in d_grads.items():
@@ -590,8 +594,11 @@ def loss_types_fixture(out_dir):
             assert (v is None) == (og[k] is None) and (v is None or rel(og[k], v) < 1e-9), (loss_type, k)
         gain = info.get("gain")
         name = loss_type if loss_type != "wgan_theirs" else ("wgan_theirs_on" if float(gain) > 0 else "wgan_theirs_off")
+        if grad_lambda == 0:
+            name += "_nopenalty"
         names.append(name)
         fx[f"{name}.seed"] = np.array(seed)
+        fx[f"{name}.grad_lambda"] = np.array(grad_lambda)
         fx[f"{name}.real"], fx[f"{name}.z"], fx[f"{name}.mix"] = real.float().numpy(), z.float().numpy(), mix.float().numpy()
         fx[f"{name}.d_loss"], fx[f"{name}.g_loss"] = d_loss.detach().numpy(), g_loss.detach().numpy()
         fx[f"{name}.d_loss32"], fx[f"{name}.g_loss32"] = d_loss32.detach().numpy(), g_loss32.detach().numpy()
