@@ -29,9 +29,9 @@ if ROOT not in sys.path:
 DEPTH, ALPHA, BATCH = 7, 1.0, 32
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # 256 CUs x 4 SIMDs x 32*32*16*2 flop / 32 cycles x 2.4 GHz
-# algorithmic conv flops of one step per sample, 8 F_G + 62 F_D (5 critic + 1 generator iteration; the
-# critic's weight gradients the reference computes and never uses are not counted)
-STEP_GFLOP_PER_SAMPLE = {7: 33.41, 0: 1.183}
+# (algorithmic conv flops of one step: config.step_flops, 8 F_G + 62 F_D per sample at every depth)
+PMC_CONV_WS = os.path.join("profiles", "r03_pmc_conv_ws_64x64_T1920_B32.csv")
+PER_KERNEL = os.path.join("profiles", "r03_bench_per_kernel.txt")
 
 
 def parse():
@@ -145,12 +145,11 @@ def conv_roofline(dev, batch, T):
     # rocprofv3 kernel trace of this command (14.96 vs 14.84 us); a pair of events around every single launch also
     # times the two event records (17.4 us) and is reported beside it as `event_pair_us`.
     achieved = flops / back_to_back / 1e12
-    # HBM bytes per launch from the PMC passes kept in profiles/*pmc_conv_ws_64x64_T1920_B32.csv:
-    # 2 x FETCH_SIZE + WRITE_SIZE = 2 x 9822.6 KiB + 15360 KiB (gfx950 tallies 128-byte read requests at
-    # 64 bytes); the algorithmic figure is 31.5 MB: input + output once, weights, multipliers.  Only valid
-    # for the profiled shape.
-    traffic = (2 * 9822.5625 + 15360.0) * 1024 if (batch, T, esize) == (32, 1920, 4.0) else None
     algorithmic_bytes = esize * 2 * batch * C * T + 4.0 * (C * C * K + C + batch * C)
+    # HBM bytes per launch of THIS kernel and shape from the two counter passes kept under profiles/ (the
+    # algorithmic figure is 31.5 MB: input + output once, weights, multipliers).  Only for the profiled shape.
+    pmc = measured_traffic() if (batch, T, esize) == (32, 1920, 4.0) else None
+    traffic = pmc["bytes"] if pmc else None
     # The kernel forms every fp32 product from three bf16 pieces per operand (six bf16 MFMAs per 16
     # reduction indices, fp32-exact to 2^-24).  `achieved`/`frac` price the ALGORITHMIC fp32 flops against
     # the fp32 matrix peak (the arithmetic type of the path); `pipe_frac` prices the six-fold executed
@@ -181,12 +180,43 @@ def conv_roofline(dev, batch, T):
            "flop_per_launch": flops, "algorithmic_bytes_per_launch": algorithmic_bytes,
            "matrix_instruction": "v_mfma_f32_32x32x2_f32" if fp32_mfma else
            "6 x v_mfma_f32_32x32x16_bf16 per 16 reduction indices (three bf16 pieces per fp32 operand)"}
+    if pmc:
+        out["traffic_over_algorithmic"] = round(traffic / algorithmic_bytes, 3)
+        out["traffic_source"] = pmc["source"]
     if not fp32_mfma:
         out["pipe_frac"] = round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4)
         ceiling = min(BF16_MFMA_PEAK_TFLOPS / 6.0, HBM_PEAK_GBS * (flops / algorithmic_bytes) / 1e3)
         out["bound_tflops"] = round(ceiling, 1)
         out["bound_frac"] = round(achieved / ceiling, 4)
     return out
+
+
+def measured_traffic():
+    """(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch of the stand-alone weight-stationary launch, from the
+    rocprofv3 counter passes committed under profiles/ (one pass per counter; gfx950 tallies a 128-byte read
+    request at 64 bytes, hence the factor two on the read side).  The file's header names the library build the
+    passes ran (``# library <id>``); the figure is reported with that id and marked when it is not the build in
+    use.  None when the file is missing."""
+    from eeggan_amd import _lib
+    path = os.path.join(ROOT, PMC_CONV_WS)
+    if not os.path.exists(path):
+        return None
+    sums, built = {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]}, None
+    for line in open(path):
+        if line.startswith("# library"):
+            built = line.split()[2]
+        if line.startswith("#") or "conv_ws_kernel" not in line:
+            continue
+        cells = line.rstrip().rsplit(",", 3)  # ..., counter, value_kib, duration_ns
+        if cells[1] in sums:
+            sums[cells[1]][0] += float(cells[2])
+            sums[cells[1]][1] += 1
+    if not (sums["FETCH_SIZE"][1] and sums["WRITE_SIZE"][1]):
+        return None
+    fetch, write = (sums[k][0] / sums[k][1] for k in ("FETCH_SIZE", "WRITE_SIZE"))
+    same = built == _lib.library_id()
+    return {"bytes": (2.0 * fetch + write) * 1024.0,
+            "source": f"{PMC_CONV_WS} (library {built}{'' if same else ', NOT the build in use: ' + _lib.library_id()})"}
 
 
 def conv_ws_family_flops(trainer_factory):
@@ -238,19 +268,27 @@ def device_info(dev):
 
 
 def in_step_figures(flops, launches):
-    """The weight-stationary family inside the training step: flops counted live, kernel time per step from
-    the committed rocprofv3 summary of this command (profiles/r02_bench_per_kernel.txt), if it is there."""
+    """The weight-stationary family inside the training step: flops counted live; kernel time per step from the
+    committed rocprofv3 kernel-trace summary of this command -- a figure of the session and box that wrote that
+    file, not of this run, which is why it carries the file's library id and is left out (``stale``) when the
+    summary belongs to another build of the library than the one in use."""
+    from eeggan_amd import _lib
     out = {"family": "conv_ws_kernel<*>", "flop_per_step": flops, "launches_per_step": launches}
-    path = os.path.join(ROOT, "profiles", "r02_bench_per_kernel.txt")
-    if os.path.exists(path):
-        ms = 0.0
-        for line in open(path):
-            if "conv_ws_kernel" in line and "ms/step=" in line:
-                ms += float(line.split("ms/step=")[1].split()[0])
-        if ms > 0:
-            out.update(kernel_ms_per_step=round(ms, 3), source="profiles/r02_bench_per_kernel.txt",
-                       achieved=round(flops / (ms * 1e-3) / 1e12, 2),
-                       frac=round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
+    path = os.path.join(ROOT, PER_KERNEL)
+    if not os.path.exists(path):
+        return out
+    ms, built = 0.0, None
+    for line in open(path):
+        if line.startswith("# library"):
+            built = line.split()[2]
+        if "conv_ws_kernel" in line and "ms/step=" in line:
+            ms += float(line.split("ms/step=")[1].split()[0])
+    out["source"] = f"{PER_KERNEL} (library {built})"
+    if built != _lib.library_id():
+        out["stale"] = f"the summary belongs to another build than the one in use ({_lib.library_id()})"
+    elif ms > 0:
+        out.update(kernel_ms_per_step=round(ms, 3), achieved=round(flops / (ms * 1e-3) / 1e12, 2),
+                   frac=round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4))
     return out
 
 
@@ -356,15 +394,9 @@ def main():
     if rank == 0:
         fam = conv_ws_family_flops(lambda: make_trainer(dev, args.depth, args.alpha, args.batch, 1373, 1, 0, eager=True))
         torch.cuda.empty_cache()
-    try:
-        tr.train()  # not timed, not counted: the first call captures the graphs
-    except Exception as exc:  # noqa: BLE001 -- any capture failure: same kernels, launched one by one
-        if args.eager:
-            raise
-        print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
-        torch.cuda.synchronize()
-        tr = make_trainer(dev, args.depth, args.alpha, args.batch, 1373, world, rank, eager=True,
-                          host_inputs=args.host_inputs, force_dist=force_dist)
+    # not timed, not counted: the first call captures the graphs.  A capture that fails ends the run with its
+    # error (a non-zero exit): the measured launch path is the captured one, or --eager when asked for.
+    tr.train()
     for _ in range(args.warmup):
         tr.train()
     barrier()
@@ -373,10 +405,17 @@ def main():
         tr.train()
     barrier()
     dt = time.perf_counter() - t0
+    ranks_reporting = 1
     if dist is not None:
-        t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        on = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], device=on, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank reports its GPU (local rank): the count of distinct reports is the number of ranks that ran
+        seen = torch.zeros(dist.get_world_size(), device=on, dtype=torch.float64)
+        seen[rank] = 1.0
+        dist.all_reduce(seen)
+        ranks_reporting = int(seen.sum().item())
     if rank == 0:
         from eeggan_amd import config
         T = config.seq_len(args.depth)
@@ -385,22 +424,26 @@ def main():
             "value": round(world * args.steps / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (reals copied from pinned host memory each iteration)" if args.host_inputs else ""),
+            "library": __import__("eeggan_amd")._lib.library_id(),
             "config": {"workload": f"final stage depth {args.depth} (T={T}, 5 ch), alpha={args.alpha:g}, 5 D + 1 G iterations "
                                    f"with Adam per step, batch {args.batch}/GPU, global batch {args.batch * world}",
                        "parallelism": f"dp{world}", "drop_noise": args.drop_mode, "activation_storage": args.storage,
                        "launch": type(tr).__name__, "device": device_info(dev)},
         }
+        if dist is not None:
+            # what the process group itself reports, so that a multi-GPU line can be checked against --gpus
+            out["config"]["dist"] = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                                     "ranks_reporting": ranks_reporting}
         out["roofline"] = conv_roofline(dev, args.batch, T)
         # (the committed per-kernel profile belongs to the headline configuration only)
         headline = args.batch == 32 and args.depth == 7 and args.alpha == 1.0 and args.dtype == "f32" and args.storage == "f32"
         if headline:
             out["roofline"]["in_step"] = in_step_figures(*fam)
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
+        step_flop = config.step_flops(args.depth, args.batch)
         out["roofline"]["whole_step"] = {
-            "flop_per_step": STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * 1e9 * args.batch,
-            "achieved": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3, 2),
-            "frac": round(STEP_GFLOP_PER_SAMPLE.get(args.depth, 0.0) * args.batch / (dt / args.steps) / 1e3
-                          / peak, 4), "peak": peak}
+            "flop_per_step": step_flop, "achieved": round(step_flop / (dt / args.steps) / 1e12, 2),
+            "frac": round(step_flop / (dt / args.steps) / 1e12 / peak, 4), "peak": peak}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.depth, args.alpha, args.batch, 1373)
         print(json.dumps(out), flush=True)

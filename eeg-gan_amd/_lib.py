@@ -155,6 +155,13 @@ def load() -> C.CDLL:
     return lib
 
 
+def library_id() -> str:
+    """First 12 hex digits of the SHA-256 of the library file in use: ties a measurement to the build it ran."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:12]
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise EegganError with the library's message on failure."""
     lib = load()

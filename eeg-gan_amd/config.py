@@ -26,6 +26,36 @@ def seq_len(depth: int) -> int:
     return t
 
 
+def stage_channels(stage: int, fmap_base: int = 1024, fmap_max: int = 256, fmap_min: int = 64) -> int:
+    """Channels of progression stage ``stage`` (reference network.py:279-280, ``nf(stage + 1)``)."""
+    return min(max(int(fmap_base / (2.0 ** (stage + 1))), fmap_min), fmap_max)
+
+
+def forward_flops(depth: int):
+    """(F_G, F_D): conv flops (2 x multiply-adds) of one generator and one critic forward pass per sample at
+    ``depth`` with alpha = 1, for the default networks: the k = 32 first layer counted with its 32 effective taps
+    on the length-1 latent, the critic's 256 + 1 channel layer, the 1x1 signal layers and the scoring layer
+    included.  One training step is 8 F_G + 62 F_D (5 critic iterations of F_G + 12 F_D and a generator
+    iteration of 3 F_G + 2 F_D; weight gradients the reference forms and never uses are not counted)."""
+    k, k0 = 3, INITIAL_KERNEL_SIZE
+    c = [stage_channels(s) for s in range(depth + 1)]
+    t = [seq_len(s) for s in range(depth + 1)]
+    conv = lambda cin, cout, taps, length: 2.0 * cin * cout * taps * length
+    f_g = conv(LATENT_SIZE, c[0], k0, 1) + conv(c[0], c[0], k, t[0])
+    f_d = conv(c[0] + 1, c[0], k, t[0]) + conv(c[0], c[0], k0, 1) + conv(c[0], 1, 1, 1)
+    for s in range(1, depth + 1):
+        f_g += conv(c[s - 1], c[s], k, t[s]) + conv(c[s], c[s], k, t[s])
+        f_d += conv(c[s], c[s], k, t[s]) + conv(c[s], c[s - 1], k, t[s])
+    f_g += conv(c[depth], NUM_CHANNELS, 1, t[depth])
+    f_d += conv(NUM_CHANNELS, c[depth], 1, t[depth])
+    return f_g, f_d
+
+
+def step_flops(depth: int, batch: int) -> float:
+    f_g, f_d = forward_flops(depth)
+    return (8.0 * f_g + 62.0 * f_d) * batch
+
+
 def shared_model_kwargs():
     return dict(initial_kernel_size=INITIAL_KERNEL_SIZE, num_rgb_channels=NUM_CHANNELS, fmap_base=1024, fmap_max=256,
                 fmap_min=64, kernel_size=3, self_attention_layers=[], progression_scale_up=PROGRESSION_SCALE_UP,

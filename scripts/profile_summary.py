@@ -10,6 +10,7 @@ AFTER the last optimizer launch are that stand-alone timing (`bench.py`'s roofli
 back to back); their mean duration is printed for comparison with the HIP-event figure in the bench line."""
 import collections
 import csv
+import os
 import re
 import sys
 
@@ -29,6 +30,9 @@ for r in window:
     agg[name][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     agg[name][1] += 1
 total = sum(v[0] for v in agg.values())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eeggan_amd import _lib  # noqa: E402
+print(f"# library {_lib.library_id()}  (the build of libeeggan_hip.so this trace ran)")
 print(f"last {steps} steps: launches/step {len(window) / steps:.1f}   kernel time/step {total / steps / 1e6:.3f} ms   "
       f"wall/step {wall / steps / 1e6:.3f} ms")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
