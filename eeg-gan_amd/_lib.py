@@ -70,6 +70,9 @@ SIGNATURES = {
     "eeggan_mbstd_fwd_static": (_i, [_f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd": (_i, [_f, _f, _f, _i, _i, _i, _i, _st]),
     "eeggan_mbstd_bwd_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_fwd_window": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_bwd_window": (_i, [_f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
+    "eeggan_mbstd_bwd_bwd_window": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
     "eeggan_wgan_gp_loss_fwd": (_i, [_f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_wgan_gp_loss_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _i, _sz, _fl, _fl, _fl, _st]),
     "eeggan_feature_match_fwd": (_i, [_f, _f, _f, _f, _i, _i, _st]),

@@ -95,38 +95,54 @@ __global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict
 }
 
 // ---- minibatch stddev --------------------------------------------------------------------------
-// Group member m owns the G samples b = g*M + m; n = C*T elements per sample.  The element axis is
-// cut into chunks of MB_CHUNK so that the grid (M x chunks) fills the chip (M is only B/4); sums over
-// all elements go through a per-(m, chunk) partial buffer and a tiny finalize kernel, in a fixed order.
+// Group member m owns the G samples b = g*M + m.  The statistics are taken over one temporal WINDOW of the
+// signal, time steps [t0, t0 + Tw) of T (reference layers.py:81-89 runs the layer once per window of
+// ``stride_size`` steps; the default is one window, Tw = T): n = C*Tw elements per sample, element e being
+// channel e / Tw at step t0 + e % Tw.  The element axis is cut into chunks of MB_CHUNK so that the grid
+// (M x chunks) fills the chip (M is only B/4); sums over all elements go through a per-(m, chunk) partial
+// buffer and a tiny finalize kernel, in a fixed order.  A launch touches only its window's columns of the
+// outputs, so a tensor with several windows takes one launch (pair) per window.
 constexpr int MB_MAXG = 8;
 constexpr int MB_CHUNK = 256;
 
-__device__ __forceinline__ float group_scale(const float* __restrict__ gout, int m, int M, int G, int n, int T,
-                                             float* red) {
-    // a[m] = (sum over the group's extra-channel gradients) / (n * G)
-    float gs = 0.f;
-    for (int i = threadIdx.x; i < G * T; i += 256) {
-        const int g = i / T, t = i - g * T;
-        gs += gout[((long long)(g * M + m)) * (n + T) + n + t];
+struct MbWin {
+    int C, T, t0, Tw;
+    __device__ __forceinline__ int n() const { return C * Tw; }                 // elements of the window per sample
+    __device__ __forceinline__ long long xs() const { return (long long)C * T; }  // sample stride of x / gx
+    __device__ __forceinline__ long long os() const { return (long long)(C + 1) * T; }  // ... of out / gout
+    __device__ __forceinline__ int off(int e) const {
+        const int c = e / Tw;
+        return c * T + t0 + (e - c * Tw);
     }
-    return block_sum_256(gs, red) / ((float)n * (float)G);
+    __device__ __forceinline__ long long extra(int t) const { return (long long)C * T + t0 + t; }  // appended channel
+};
+
+__device__ __forceinline__ float group_scale(const float* __restrict__ gout, int m, int M, int G, const MbWin& w,
+                                             float* red) {
+    // a[m] = (sum over the group's extra-channel gradients inside the window) / (n * G)
+    float gs = 0.f;
+    for (int i = threadIdx.x; i < G * w.Tw; i += 256) {
+        const int g = i / w.Tw, t = i - g * w.Tw;
+        gs += gout[(long long)(g * M + m) * w.os() + w.extra(t)];
+    }
+    return block_sum_256(gs, red) / ((float)w.n() * (float)G);
 }
 
 __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                        float* __restrict__ ws, int M, int G, int C, int T) {
+                                                        float* __restrict__ ws, int M, int G, MbWin w) {
     __shared__ float red[4];
     const int m = blockIdx.x, chunk = blockIdx.y;
-    const int n = C * T;
     const float invG = 1.f / (float)G;
     const int e = chunk * MB_CHUNK + threadIdx.x;
     float sd = 0.f;
-    if (e < n) {
+    if (e < w.n()) {
+        const int o = w.off(e);
         float v[MB_MAXG];
         float mu = 0.f;
 #pragma unroll
         for (int g = 0; g < MB_MAXG; ++g)
             if (g < G) {
-                v[g] = x[((long long)(g * M + m)) * n + e];
+                v[g] = x[(long long)(g * M + m) * w.xs() + o];
                 mu += v[g];
             }
         mu *= invG;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict_
             if (g < G) {
                 const float d = v[g] - mu;
                 var += d * d;
-                out[((long long)(g * M + m)) * (n + T) + e] = v[g];  // channels [0, C) are a copy of x
+                out[(long long)(g * M + m) * w.os() + o] = v[g];  // channels [0, C) are a copy of x
             }
         sd = sqrtf(var * invG);
     }
@@ -144,35 +160,35 @@ __global__ __launch_bounds__(256) void mbstd_fwd_kernel(const float* __restrict_
     if (threadIdx.x == 0) ws[m * gridDim.y + chunk] = tot;
 }
 
-// out[b, C, t] = scale * sum_chunk ws[m][chunk] for the G samples of member m
+// out[b, C, t0 + t] = scale * sum_chunk ws[m][chunk] for the G samples of member m
 __global__ __launch_bounds__(256) void mbstd_finalize_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                             int M, int G, int n, int T, int nchunks, float scale) {
+                                                             int M, int G, MbWin w, int nchunks, float scale) {
     __shared__ float red[4];
     const int m = blockIdx.x;
     float s = 0.f;
     for (int i = threadIdx.x; i < nchunks; i += 256) s += ws[m * nchunks + i];
     const float tot = block_sum_256(s, red) * scale;
-    for (int i = threadIdx.x; i < G * T; i += 256) {
-        const int g = i / T, t = i - g * T;
-        out[((long long)(g * M + m)) * (n + T) + n + t] = tot;
+    for (int i = threadIdx.x; i < G * w.Tw; i += 256) {
+        const int g = i / w.Tw, t = i - g * w.Tw;
+        out[(long long)(g * M + m) * w.os() + w.extra(t)] = tot;
     }
 }
 
 __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
-                                                        float* __restrict__ gx, int M, int G, int C, int T) {
+                                                        float* __restrict__ gx, int M, int G, MbWin w) {
     __shared__ float red[4];
     const int m = blockIdx.x, chunk = blockIdx.y;
-    const int n = C * T;
     const float invG = 1.f / (float)G;
-    const float a = group_scale(gout, m, M, G, n, T, red);
+    const float a = group_scale(gout, m, M, G, w, red);
     const int e = chunk * MB_CHUNK + threadIdx.x;
-    if (e >= n) return;
+    if (e >= w.n()) return;
+    const int o = w.off(e);
     float v[MB_MAXG];
     float mu = 0.f;
 #pragma unroll
     for (int g = 0; g < MB_MAXG; ++g)
         if (g < G) {
-            v[g] = x[((long long)(g * M + m)) * n + e];
+            v[g] = x[(long long)(g * M + m) * w.xs() + o];
             mu += v[g];
         }
     mu *= invG;
@@ -188,30 +204,30 @@ __global__ __launch_bounds__(256) void mbstd_bwd_kernel(const float* __restrict_
     for (int g = 0; g < MB_MAXG; ++g)
         if (g < G) {
             const long long b = g * M + m;
-            gx[b * n + e] = gout[b * (n + T) + e] + a * (v[g] - mu) * inv_sigma;
+            gx[b * w.xs() + o] = gout[b * w.os() + o] + a * (v[g] - mu) * inv_sigma;
         }
 }
 
 __global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
                                                             const float* __restrict__ q, float* __restrict__ ggout,
                                                             float* __restrict__ gx2, float* __restrict__ ws, int M,
-                                                            int G, int C, int T) {
+                                                            int G, MbWin w) {
     __shared__ float red[4];
     const int m = blockIdx.x, chunk = blockIdx.y;
-    const int n = C * T;
     const float invG = 1.f / (float)G;
-    const float a = group_scale(gout, m, M, G, n, T, red);
+    const float a = group_scale(gout, m, M, G, w, red);
     const int e = chunk * MB_CHUNK + threadIdx.x;
     float qr = 0.f;  // sum_g q_g * R_g of this element
-    if (e < n) {
+    if (e < w.n()) {
+        const int o = w.off(e);
         float v[MB_MAXG], qv[MB_MAXG];
         float mu = 0.f, qm = 0.f;
 #pragma unroll
         for (int g = 0; g < MB_MAXG; ++g)
             if (g < G) {
                 const long long b = g * M + m;
-                v[g] = x[b * n + e];
-                qv[g] = q[b * n + e];
+                v[g] = x[b * w.xs() + o];
+                qv[g] = q[b * w.xs() + o];
                 mu += v[g];
                 qm += qv[g];
             }
@@ -234,8 +250,8 @@ __global__ __launch_bounds__(256) void mbstd_bwd_bwd_kernel(const float* __restr
             if (g < G) {
                 const long long b = g * M + m;
                 const float R = (v[g] - mu) * inv_sigma;
-                gx2[b * n + e] = a * inv_sigma * ((qv[g] - qm) - R * qrm);
-                ggout[b * (n + T) + e] = qv[g];
+                gx2[b * w.xs() + o] = a * inv_sigma * ((qv[g] - qm) - R * qrm);
+                ggout[b * w.os() + o] = qv[g];
             }
     }
     const float tot = block_sum_256(qr, red);
@@ -249,6 +265,12 @@ int mb_check(const char* what, int B, int C, int T, int group, int* G, int* M) {
     EEGGAN_REQUIRE(B % *G == 0, "%s: batch %d not divisible by group size %d", what, B, *G);
     EEGGAN_REQUIRE((long long)C * T < (1ll << 24), "%s: C*T too large", what);
     *M = B / *G;
+    return 0;
+}
+
+int win_check(const char* what, int T, int t0, int Tw) {
+    EEGGAN_REQUIRE(t0 >= 0 && Tw > 0 && t0 + Tw <= T, "%s: window [%d, %d) outside the signal's %d steps", what, t0,
+                   t0 + Tw, T);
     return 0;
 }
 
@@ -376,14 +398,20 @@ extern "C" size_t eeggan_mbstd_workspace(int B, int C, int T, int group) {
 
 extern "C" int eeggan_mbstd_fwd(const float* x, float* out, void* workspace, int B, int C, int T, int group,
                                 void* stream) {
+    return eeggan_mbstd_fwd_window(x, out, workspace, B, C, T, 0, T, group, stream);
+}
+
+extern "C" int eeggan_mbstd_fwd_window(const float* x, float* out, void* workspace, int B, int C, int T, int t0, int Tw,
+                                       int group, void* stream) {
     int G, M;
-    if (mb_check("mbstd_fwd", B, C, T, group, &G, &M)) return 1;
+    if (mb_check("mbstd_fwd", B, C, T, group, &G, &M) || win_check("mbstd_fwd", T, t0, Tw)) return 1;
     EEGGAN_REQUIRE(x && out && workspace, "mbstd_fwd: null pointer");
-    const int n = C * T, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
+    const MbWin w{C, T, t0, Tw};
+    const int n = C * Tw, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
     float* ws = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, C, T);
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, w);
     if (check_launch("mbstd_fwd")) return 1;
-    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, n, T, nch,
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, w, nch,
                        1.f / (float)n);
     return check_launch("mbstd_fwd finalize");
 }
@@ -401,34 +429,48 @@ extern "C" int eeggan_mbstd_fwd_static(const float* x, float* out, int B, int C,
     if (scratch_for_current_device("mbstd_fwd_static", &ws)) return 1;
     // every partial sum the finalize kernel reads is written by the first kernel of this call: nothing of
     // an earlier call's contents is read, so nothing needs clearing
-    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, C, T);
+    const MbWin w{C, T, 0, T};
+    hipLaunchKernelGGL(mbstd_fwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, out, ws, M, G, w);
     if (check_launch("mbstd_fwd_static")) return 1;
-    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, n, T, nch,
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, out, M, G, w, nch,
                        1.f / (float)n);
     return check_launch("mbstd_fwd_static finalize");
 }
 
 extern "C" int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C, int T, int group,
                                 void* stream) {
+    return eeggan_mbstd_bwd_window(x, gout, gx, B, C, T, 0, T, group, stream);
+}
+
+extern "C" int eeggan_mbstd_bwd_window(const float* x, const float* gout, float* gx, int B, int C, int T, int t0, int Tw,
+                                       int group, void* stream) {
     int G, M;
-    if (mb_check("mbstd_bwd", B, C, T, group, &G, &M)) return 1;
+    if (mb_check("mbstd_bwd", B, C, T, group, &G, &M) || win_check("mbstd_bwd", T, t0, Tw)) return 1;
     EEGGAN_REQUIRE(x && gout && gx, "mbstd_bwd: null pointer");
-    const int nch = (C * T + MB_CHUNK - 1) / MB_CHUNK;
-    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, gout, gx, M, G, C, T);
+    const MbWin w{C, T, t0, Tw};
+    const int nch = (C * Tw + MB_CHUNK - 1) / MB_CHUNK;
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, gout, gx, M, G, w);
     return check_launch("mbstd_bwd");
 }
 
 extern "C" int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
                                     void* workspace, int B, int C, int T, int group, void* stream) {
+    return eeggan_mbstd_bwd_bwd_window(x, gout, q, ggout, gx2, workspace, B, C, T, 0, T, group, stream);
+}
+
+extern "C" int eeggan_mbstd_bwd_bwd_window(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
+                                           void* workspace, int B, int C, int T, int t0, int Tw, int group,
+                                           void* stream) {
     int G, M;
-    if (mb_check("mbstd_bwd_bwd", B, C, T, group, &G, &M)) return 1;
+    if (mb_check("mbstd_bwd_bwd", B, C, T, group, &G, &M) || win_check("mbstd_bwd_bwd", T, t0, Tw)) return 1;
     EEGGAN_REQUIRE(x && gout && q && ggout && gx2 && workspace, "mbstd_bwd_bwd: null pointer");
-    const int n = C * T, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
+    const MbWin w{C, T, t0, Tw};
+    const int n = C * Tw, nch = (n + MB_CHUNK - 1) / MB_CHUNK;
     float* ws = static_cast<float*>(workspace);
     hipLaunchKernelGGL(mbstd_bwd_bwd_kernel, dim3(M, nch), dim3(256), 0, as_stream(stream), x, gout, q, ggout, gx2, ws,
-                       M, G, C, T);
+                       M, G, w);
     if (check_launch("mbstd_bwd_bwd")) return 1;
-    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, ggout, M, G, n, T, nch,
+    hipLaunchKernelGGL(mbstd_finalize_kernel, dim3(M), dim3(256), 0, as_stream(stream), ws, ggout, M, G, w, nch,
                        1.f / ((float)n * (float)G));
     return check_launch("mbstd_bwd_bwd finalize");
 }

@@ -2,9 +2,10 @@
 ``layers.py``; every forward runs fused HIP kernels (see ``ops.py``).
 
 Supported: the options the default configuration uses (reference defaults.yml:16-58) plus ReLU / linear layers,
-non-equalized layers and the other initialisers.  Separable layers (a depthwise conv followed
-by a 1x1 conv, layers.py:137-147) self attention (layers.py:41-64) and batch norm in the generator's layers, plain or modulated by the latent
-(layers.py:93-134), run too.  Options outside that set (spectral norm, class conditioning) raise
+non-equalized layers, the other initialisers, separable layers (a depthwise conv followed by a 1x1 conv,
+layers.py:137-147), self attention (layers.py:41-64), batch norm plain, modulated by the latent or conditioned on a
+class embedding (layers.py:93-134), spectral norm (layers.py:170-171) and MinibatchStddev over several temporal
+windows (layers.py:81-89).  What is left out (strided convs, GDrop axes other than (0, 1)) raises
 ``NotImplementedError`` at construction: there is no second code path.
 """
 from __future__ import annotations
@@ -130,6 +131,36 @@ class _DropPool:
 _drop_pool = _DropPool()
 
 
+_forced_masks = None
+
+
+class forced_masks:
+    """Context manager for parity tests: inside it the LeakyReLU layers of the critic's default form (conv ->
+    LeakyReLU -> GDrop, reference layers.py:196-213) take the branch of every output from the next tensor of
+    ``masks`` (its sign; one [B, Cout, T] tensor per layer call, in call order) instead of from their own
+    pre-activations.  With the branches of a reference run, the layers compute the reference's piecewise-linear
+    function exactly, so gradients can be compared without the noise of branches that flip under rounding."""
+
+    def __init__(self, masks):
+        self.masks = iter(masks)
+
+    def __enter__(self):
+        global _forced_masks
+        self.prev, _forced_masks = _forced_masks, self
+        return self
+
+    def __exit__(self, *exc):
+        global _forced_masks
+        _forced_masks = self.prev
+        return False
+
+    def next_for(self, shape):
+        m = next(self.masks)
+        if tuple(m.shape) != tuple(shape):
+            raise RuntimeError(f"forced_masks: the next mask has shape {tuple(m.shape)}, the layer's output {tuple(shape)}")
+        return m.to(ops._act_dtype(shape[1], shape[2]))  # (the storage type of this layer's output)
+
+
 def drop_pool_reset() -> None:
     _drop_pool.reset()
 
@@ -186,10 +217,9 @@ class MinibatchStddev(nn.Module):
     def forward(self, x):
         if self.group_size < 0:
             return x
-        if x.shape[2] > self.stride_size:
-            raise NotImplementedError("MinibatchStddev: more than one temporal window is not supported")
         per_segment = x.shape[0] // _segments
-        return ops.minibatch_stddev(x, int(min(per_segment, self.group_size)), _segments)
+        # statistics per temporal window of ``stride_size`` steps (layers.py:81-89); the default is one window
+        return ops.minibatch_stddev(x, int(min(per_segment, self.group_size)), _segments, self.stride_size)
 
 
 class ConditionalBatchNorm(nn.Module):
@@ -517,7 +547,9 @@ class GeneralConv(nn.Module):
                 raise NotImplementedError("linear conv with drop / full-length kernel is not supported")
             return ops.conv1d(x, w, b, None, s, ACT_NONE, flip=c._flip)
         if kind == "same":
-            return ops.conv1d(x, w, b, self._multipliers(x), s, ACT_LRELU, slope, flip=c._flip)
+            forced = None if _forced_masks is None else _forced_masks.next_for((x.shape[0], w.shape[0], x.shape[2]))
+            return ops.conv1d(x, w, b, self._multipliers(x), s, ACT_LRELU, slope, flip=c._flip, forced_mask=forced)
         if kind == "tail":
-            return ops.tail_conv(x, w, b, self._multipliers(x), s, slope)
+            forced = None if _forced_masks is None else _forced_masks.next_for((x.shape[0], w.shape[0], 1))
+            return ops.tail_conv(x, w, b, self._multipliers(x), s, slope, forced_mask=forced)
         raise NotImplementedError("the length-1 (head) conv is only supported with pixel norm")

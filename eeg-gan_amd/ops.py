@@ -685,14 +685,22 @@ class _Conv(Function):
     """y = drop * act(bias + conv(in_scale * x, w)), act in {none, leaky-relu}; twice differentiable."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, drop, in_scale, act, slope, flip=None):
+    def forward(ctx, x, w, bias, drop, in_scale, act, slope, flip=None, forced=None):
         ctx.flip = flip
         if act not in (ACT_NONE, ACT_LRELU):
             raise ValueError("_Conv supports linear and leaky-relu epilogues")
         if act == ACT_NONE and drop is not None:
             raise ValueError("a drop multiplier needs the leaky-relu epilogue")
-        y = conv1d_raw(x, w, bias, drop, in_scale=in_scale, act=act, act_param=slope)
-        ctx.save_for_backward(x, w, drop, y if act == ACT_LRELU else None, bias)
+        if forced is not None:
+            # the LeakyReLU branch of every output is GIVEN (sign of ``forced``) instead of taken from the
+            # pre-activation's own sign: the layer is then linear in x and w, forward and backward
+            if act != ACT_LRELU:
+                raise ValueError("a forced mask needs the leaky-relu epilogue")
+            y = conv1d_raw(x, w, bias, drop, in_scale=in_scale, act=ACT_MASK, act_param=slope, act_aux=forced)
+            ctx.save_for_backward(x, w, drop, forced, bias)
+        else:
+            y = conv1d_raw(x, w, bias, drop, in_scale=in_scale, act=act, act_param=slope)
+            ctx.save_for_backward(x, w, drop, y if act == ACT_LRELU else None, bias)
         ctx.in_scale, ctx.slope, ctx.has_bias = in_scale, slope, bias is not None
         return y
 
@@ -712,12 +720,14 @@ class _Conv(Function):
                 _direct.wgrad(w, bias, x, gy, ctx.in_scale, y, drop, ctx.slope)
             else:
                 gw, gb = _WGrad.apply(x, gy, w.shape[2], ctx.in_scale, ctx.has_bias, y, drop, ctx.slope)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None):
-    """Fused equalized conv layer of the discriminator path (twice differentiable)."""
-    return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip)
+def conv1d(x, w, bias, drop, in_scale, act, slope=0.0, flip=None, forced_mask=None):
+    """Fused equalized conv layer of the discriminator path (twice differentiable).  ``forced_mask`` ([B, Cout, T],
+    its sign picks each output's LeakyReLU branch): the branches are given instead of following the pre-activations
+    (parity tests hold the kernels to a reference under the reference's own branches)."""
+    return _Conv.apply(x, w, bias, drop, float(in_scale), int(act), float(slope), flip, forced_mask)
 
 
 # --------------------------------------------------------------------------------------- depthwise conv
@@ -874,10 +884,15 @@ class _Tail(Function):
     """y[B, Cout, 1] = drop * lrelu(bias + sum_{ci,t} w[co,ci,t] * in_scale * x[b,ci,t]); twice differentiable."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, drop, in_scale, slope):
+    def forward(ctx, x, w, bias, drop, in_scale, slope, forced=None):
         x = _chk(x, "tail x")
-        y = _tail_fwd_raw(x, w, bias, drop, in_scale, ACT_LRELU, slope)
-        ctx.save_for_backward(x, w, drop, y)
+        if forced is not None:  # given LeakyReLU branches (see conv1d): the linear layer, then the mask and multipliers
+            lin = _tail_fwd_raw(x, w, bias, None, in_scale, ACT_NONE, 0.0)
+            y = lrelu_drop_bwd_raw(lin, forced, drop, slope)
+            ctx.save_for_backward(x, w, drop, forced)
+        else:
+            y = _tail_fwd_raw(x, w, bias, drop, in_scale, ACT_LRELU, slope)
+            ctx.save_for_backward(x, w, drop, y)
         ctx.in_scale, ctx.slope, ctx.has_bias = in_scale, slope, bias is not None
         return y
 
@@ -890,13 +905,13 @@ class _Tail(Function):
             gx = _TailT.apply(gc, w, ctx.in_scale)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _input_grad_only:
             gw, gb = _TailWGrad.apply(x, gc, ctx.in_scale, ctx.has_bias)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def tail_conv(x, w, bias, drop, in_scale, slope):
+def tail_conv(x, w, bias, drop, in_scale, slope, forced_mask=None):
     if x.shape[2] != w.shape[2]:
         raise RuntimeError(f"tail conv: signal length {x.shape[2]} must equal the kernel size {w.shape[2]}")
-    return _Tail.apply(x, w, bias, drop, float(in_scale), float(slope))
+    return _Tail.apply(x, w, bias, drop, float(in_scale), float(slope), forced_mask)
 
 
 # --------------------------------------------------------------------------------------- G-path layers
@@ -1639,17 +1654,24 @@ def _seg(t, i, bs):
     return t.data_ptr() + i * bs * (t.numel() // t.shape[0]) * 4
 
 
+def _windows(T, stride):
+    """(start, length) of the temporal windows the layer takes its statistics over (reference layers.py:81-83)."""
+    return [(t0, min(stride, T - t0)) for t0 in range(0, T, stride)]
+
+
 class _MbStdBwd(Function):
     @staticmethod
-    def forward(ctx, x, gout, group, segments):
+    def forward(ctx, x, gout, group, segments, stride):
         gout = _chk(gout, "mbstd gout")
         B, Cc, T = x.shape
         bs = B // segments
         gx = torch.empty_like(x)
         for i in range(segments):
-            call("eeggan_mbstd_bwd", _seg(x, i, bs), _seg(gout, i, bs), _seg(gx, i, bs), bs, Cc, T, group, _stream())
+            for t0, tw in _windows(T, stride):
+                call("eeggan_mbstd_bwd_window", _seg(x, i, bs), _seg(gout, i, bs), _seg(gx, i, bs), bs, Cc, T, t0, tw,
+                     group, _stream())
         ctx.save_for_backward(x, gout)
-        ctx.group, ctx.segments = group, segments
+        ctx.group, ctx.segments, ctx.stride = group, segments, stride
         return gx
 
     @staticmethod
@@ -1662,15 +1684,16 @@ class _MbStdBwd(Function):
         ggout = torch.empty_like(gout)
         gx2 = torch.empty_like(x)
         for i in range(ctx.segments):
-            ws = _mbstd_ws(bs, Cc, T, ctx.group, x.device)
-            call("eeggan_mbstd_bwd_bwd", _seg(x, i, bs), _seg(gout, i, bs), _seg(q, i, bs), _seg(ggout, i, bs),
-                 _seg(gx2, i, bs), ws.data_ptr(), bs, Cc, T, ctx.group, _stream())
-        return gx2, ggout, None, None
+            for t0, tw in _windows(T, ctx.stride):
+                ws = _mbstd_ws(bs, Cc, T, ctx.group, x.device)
+                call("eeggan_mbstd_bwd_bwd_window", _seg(x, i, bs), _seg(gout, i, bs), _seg(q, i, bs), _seg(ggout, i, bs),
+                     _seg(gx2, i, bs), ws.data_ptr(), bs, Cc, T, t0, tw, ctx.group, _stream())
+        return gx2, ggout, None, None, None
 
 
 class _MbStd(Function):
     @staticmethod
-    def forward(ctx, x, group, segments):
+    def forward(ctx, x, group, segments, stride):
         x = _chk(x, "mbstd x")
         B, Cc, T = x.shape
         if B % segments:
@@ -1678,20 +1701,27 @@ class _MbStd(Function):
         bs = B // segments
         out = torch.empty((B, Cc + 1, T), device=x.device, dtype=torch.float32)
         for i in range(segments):
-            ws = _mbstd_ws(bs, Cc, T, group, x.device)
-            call("eeggan_mbstd_fwd", _seg(x, i, bs), _seg(out, i, bs), ws.data_ptr(), bs, Cc, T, group, _stream())
+            for t0, tw in _windows(T, stride):
+                ws = _mbstd_ws(bs, Cc, T, group, x.device)
+                call("eeggan_mbstd_fwd_window", _seg(x, i, bs), _seg(out, i, bs), ws.data_ptr(), bs, Cc, T, t0, tw, group,
+                     _stream())
         ctx.save_for_backward(x)
-        ctx.group, ctx.segments = group, segments
+        ctx.group, ctx.segments, ctx.stride = group, segments, stride
         return out
 
     @staticmethod
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
-        return _MbStdBwd.apply(x, gout, ctx.group, ctx.segments), None, None
+        return _MbStdBwd.apply(x, gout, ctx.group, ctx.segments, ctx.stride), None, None, None
 
 
-def minibatch_stddev(x, group, segments=1):
-    return _MbStd.apply(x, int(group), int(segments))
+def minibatch_stddev(x, group, segments=1, stride=None):
+    """MinibatchStddev (reference layers.py:67-90): ``stride`` is the length of a temporal window (default: the
+    whole signal, one window)."""
+    stride = int(x.shape[2] if stride is None else stride)
+    if stride < 1:
+        raise ValueError("minibatch_stddev: the temporal window must hold at least one step")
+    return _MbStd.apply(x, int(group), int(segments), stride)
 
 
 # --------------------------------------------------------------------------------------- losses

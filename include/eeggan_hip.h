@@ -260,6 +260,17 @@ int eeggan_mbstd_bwd(const float* x, const float* gout, float* gx, int B, int C,
                      void* stream);
 int eeggan_mbstd_bwd_bwd(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
                          void* workspace, int B, int C, int T, int group, void* stream);
+/* The same three passes on ONE temporal window, time steps [t0, t0 + Tw) of T: the reference's layer with
+ * temporal_groups_per_window > 1 takes its statistics per window of kernel_size / temporal_groups_per_window steps
+ * (layers.py:72, 81-89).  A call reads and writes only its window's columns of every tensor (all still [B, C(+1), T]),
+ * so a signal of several windows takes one call per window; with t0 = 0, Tw = T they are the calls above.  The
+ * workspace of eeggan_mbstd_workspace(B, C, T, group) is large enough for any window. */
+int eeggan_mbstd_fwd_window(const float* x, float* out, void* workspace, int B, int C, int T, int t0, int Tw,
+                            int group, void* stream);
+int eeggan_mbstd_bwd_window(const float* x, const float* gout, float* gx, int B, int C, int T, int t0, int Tw,
+                            int group, void* stream);
+int eeggan_mbstd_bwd_bwd_window(const float* x, const float* gout, const float* q, float* ggout, float* gx2,
+                                void* workspace, int B, int C, int T, int t0, int Tw, int group, void* stream);
 
 /* ---- WGAN-GP loss (losses.py:94-100,114-119 and 47-48) -----------------------------------
  * loss = mean(d_fake) - mean(d_real) + drift*mean(d_real^2) + lambda/target^2 * mean((|g_b|_2 - target)^2)

@@ -51,6 +51,7 @@ class NetConfig:
     g_dropout: float = 0.2
     d_dropout: float = 0.2
     group_size: int = 4
+    temporal_groups_per_window: int = 1    # MinibatchStddev windows of initial_kernel_size / this many steps (layers.py:72)
     tanh_scale: float = 0.5
     # options beside the defaults (network.py:152-153, 225-230, 400-401, 453-457)
     residual: bool = False                 # identity / 1x1-conv skips around every block but the 32-sample ones
@@ -342,8 +343,7 @@ def alpha_fade_reals(x, depth: int, alpha: float, cfg: "NetConfig" = None):
 
 
 def minibatch_stddev(x, group_size: int = 4, window: int = 32):
-    """layers.py:74-90 with temporal_groups_per_window=1: per window of
-    ``window`` time steps, samples are split into ``G=min(B, group_size)``
+    """layers.py:74-90: per window of ``window`` = kernel_size // temporal_groups_per_window time steps, samples are split into ``G=min(B, group_size)``
     interleaved groups (sample i sits with i + B/G, ...); the per-(member,
     channel, time) standard deviation over the group (no epsilon) is averaged
     over channels and time and appended as one extra channel."""
@@ -423,7 +423,7 @@ def d_block(params, scales, pos: int, h, cfg: NetConfig, src: "DropSource", firs
         x = h
         base = 0  # (without MinibatchStddev, network.py:405-406, the convs are net.0, net.1, ...)
         if cfg.group_size >= 0:
-            h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size)
+            h = minibatch_stddev(h, cfg.group_size, cfg.initial_kernel_size // cfg.temporal_groups_per_window)
             base = 1
         n = base + (3 if cfg.deep else 1)  # (deep: two more layers in the middle, network.py:411-415)
         for i in range(base, n):

@@ -196,6 +196,18 @@ def test_stated_bounds_against_reference_fixture(dev, bf16_storage, name):
     run_bounds(dev, name, "bf16 storage", FWD_BOUND, SUMMED_BOUND, GRAD_BOUND)
 
 
+BRANCH_BOUND, BRANCH_BIAS_BOUND = 2e-2, 1.5e-1
+
+
+@pytest.mark.parametrize("depth,alpha,B", [(7, 1.0, 8), (7, 0.5, 8)])
+def test_gradients_under_reference_branches(dev, bf16_storage, depth, alpha, B):
+    """The mode with every LeakyReLU branch of the critic taken from the fp64 oracle: every term's gradient of every
+    tensor within 2e-2 of its own norm (bf16 operands and bf16-stored activations, no branch flips); the penalty
+    term's bias gradients, sums that cancel to a few per cent of their terms, within 1.5e-1 (test_bf16_mode.py)."""
+    from test_bf16_mode import run_branch_bound
+    run_branch_bound(dev, depth, alpha, B, "bf16 storage", BRANCH_BOUND, BRANCH_BIAS_BOUND)
+
+
 def test_graph_trainer_runs_in_the_mode(dev, bf16_storage):
     """The benchmarked launch path (graphs, stacked pass, grouped weight gradients) with bfloat16 activations:
     finite losses, parameters that move, float32 parameters and gradients."""

@@ -26,6 +26,53 @@ pytestmark = pytest.mark.gpu
 # Largest ratio measured on the five fixtures: 0.8 (per term), see the printed "worst deviation" lines.
 NOISE_FACTOR = 2.0
 
+# Book-keeping of the gates below: every tensor they see is recorded as (name, deviation, tolerance without the
+# conditioning term = max(1e-4, NOISE_FACTOR x noise), full tolerance).  ``_gate_report`` prints the table of the
+# tensors that pass ONLY through the conditioning term and bounds how many and how far they may be: a systematic
+# kernel error would show as many such tensors, or as one far above its noise-only tolerance.
+COND_ONLY_FAR = 3.0             # "far": a deviation above this many times the tensor's noise-only tolerance ...
+COND_ONLY_MAX_FAR = 0.1         # ... which at most this share of a test's tensors may show (two at least)
+COND_ONLY_MAX_RATIO = 25.0      # and no deviation may exceed this many times its noise-only tolerance (COND_CAP / 2e-4)
+
+
+class _GateLog:
+    """``family``: tensors whose deviations have ONE common cause count once in the bound on far outliers, with
+    the family's median ratio (the generator's gradients are all linear images of one tensor, the gradient the
+    critic hands back: a LeakyReLU branch that differs in the critic moves every one of them together)."""
+
+    def __init__(self):
+        self.rows, self.family = [], {}
+
+    def add(self, name, e, tol_noise, tol, family=None):
+        self.rows.append((name, e, tol_noise, tol))
+        if family is not None:
+            self.family[name] = family
+
+    def report(self, what):
+        cond_only = [r for r in self.rows if r[1] >= r[2]]
+        print(f"{what}: {len(self.rows)} tensors, {len(cond_only)} pass only through the conditioning term")
+        for name, e, tol_noise, tol in sorted(cond_only, key=lambda r: -r[1] / r[2]):
+            print(f"    {name:48s} deviation {e:.2e} = {e / tol_noise:5.1f} x its noise-only tolerance {tol_noise:.1e} "
+                  f"(gate {tol:.1e})")
+        worst = max((r[1] / r[3] for r in self.rows), default=0.0)
+        print(f"    worst deviation / gate over all tensors: {worst:.2f}")
+        ratios, families = [], {}
+        for name, e, tol_noise, _ in self.rows:
+            if name in self.family:
+                families.setdefault(self.family[name], []).append(e / tol_noise)
+            else:
+                ratios.append(e / tol_noise)
+        for fam, values in families.items():
+            ratios.append(sorted(values)[len(values) // 2])
+            print(f"    family {fam}: {len(values)} tensors with one upstream cause, median deviation "
+                  f"{ratios[-1]:.1f} x the noise-only tolerance")
+        far = [r for r in ratios if r >= COND_ONLY_FAR]
+        assert len(far) <= max(2, COND_ONLY_MAX_FAR * len(ratios)), \
+            f"{what}: {len(far)} of {len(self.rows)} tensors lie more than {COND_ONLY_FAR:g} x above their noise-only tolerance"
+        for name, e, tol_noise, _ in cond_only:
+            assert e < COND_ONLY_MAX_RATIO * tol_noise, f"{what}, {name}: {e:.2e} is {e / tol_noise:.0f} x its noise-only tolerance"
+
+
 E2E = ["e2e_d0_a1", "e2e_d1_a05", "e2e_d4_a1", "e2e_d7_a1", "e2e_d7_a05"]
 
 
@@ -100,6 +147,7 @@ def _check_d_terms(fx, g, d, real, z, mix, seed):
     tensor, the measured conditioning of that tensor).  Returns the conditioning per tensor."""
     base = _term_grads(d, g, real, z, mix, seed)
     names = [k for k, _ in d.named_parameters()]
+    log = _GateLog()
     cond = {k: 0.0 for k in names}
     gen = torch.Generator(device=real.device).manual_seed(seed)
     for _ in range(COND_TRIALS):
@@ -125,13 +173,16 @@ def _check_d_terms(fx, g, d, real, z, mix, seed):
             # of its three terms (single-term figures are single draws and scatter by 10x)
             noise = max(float(fx[f"d_term_{t}_noise.{k}"]) for t in ("real", "fake", "gp")
                         if f"d_term_{t}_noise.{k}" in fx)
-            tol = max(1e-4, NOISE_FACTOR * noise, cond[k])
+            tol_noise = max(1e-4, NOISE_FACTOR * noise)
+            tol = max(tol_noise, cond[k])
             e64, e32 = rel(subsample(gr), fx[key]), rel(subsample(gr), fx[f"d_term_{term}_sub32.{k}"])
             assert min(e64, e32) < tol, (f"critic term '{term}', {k}: differs by {e64:.3e} (fp64 ref) / {e32:.3e} "
                                          f"(fp32 ref), tolerance {tol:.3e} (reference noise {noise:.1e}, "
                                          f"conditioning {cond[k]:.1e})")
+            log.add(f"{term}.{k}", min(e64, e32), tol_noise, tol)
             worst = max(worst, (min(e64, e32) / max(noise, 2.5e-5), f"{term}.{k}"))
     print(f"critic terms: worst deviation = {worst[0]:.2f} x the reference's own fp32-vs-fp64 distance ({worst[1]})")
+    log.report("critic terms")
     return cond
 
 
@@ -202,7 +253,7 @@ def ops_mean_neg(v):
     return ops.mean_scale(v, -1.0)
 
 
-def _oracle_gate(name, got, ref64, ref32, worst, scale=None, cond=0.0):
+def _oracle_gate(name, got, ref64, ref32, worst, scale=None, cond=0.0, log=None, family=None):
     """Gate for a gradient checked against the oracle run on this machine in BOTH precisions: the fp32 oracle
     run is one draw of the rounding noise of this gradient (LeakyReLU mask flips, see above), so the tensor
     must lie within max(1e-4, NOISE_FACTOR x |ref32 - ref64|) of the fp64 run or of the fp32 run.  ``scale``:
@@ -218,11 +269,14 @@ def _oracle_gate(name, got, ref64, ref32, worst, scale=None, cond=0.0):
         return float((a - b).norm()) / (float(b.norm()) if scale is None else scale)
 
     noise = dev(ref32, ref64)
-    tol = max(1e-4, NOISE_FACTOR * noise, min(NOISE_FACTOR * cond, COND_CAP))
+    tol_noise = max(1e-4, NOISE_FACTOR * noise)
+    tol = max(tol_noise, min(NOISE_FACTOR * cond, COND_CAP))
     e64, e32 = dev(got, ref64), dev(got, ref32)
     e = min(e64, e32)
     assert e < tol, (f"{name}: differs by {e64:.3e} (fp64 oracle) / {e32:.3e} (fp32 oracle), tolerance {tol:.3e} "
                      f"(oracle fp32-vs-fp64 {noise:.1e}, conditioning {cond:.1e})")
+    if log is not None:
+        log.add(name, e, tol_noise, tol, family)
     return max(worst, (e / max(noise, 2.5e-5), name))
 
 
@@ -358,13 +412,129 @@ def test_headline_configuration_against_oracle(dev):
         for i, (a, b) in enumerate(zip(grads, pert)):
             if a is not None:
                 cond[i] = max(cond[i], float((a - b).norm()) / scales[i])
-    worst = (0.0, "")
+    worst, log = (0.0, ""), _GateLog()
     for (k, p), got, gr, gr32, sc, cd in zip(d.named_parameters(), grads, grads_ref, grads_ref32, scales, cond):
         if gr is None:
             assert got is None, k
         else:
-            worst = _oracle_gate(k, got, gr, gr32, worst, sc, cd)
+            worst = _oracle_gate(k, got, gr, gr32, worst, sc, cd, log)
     print(f"headline configuration: worst deviation = {worst[0]:.2f} x the oracle's fp32-vs-fp64 distance ({worst[1]})")
+    log.report("headline configuration")
+
+
+def _taped_oracle_critic_iteration(O, dp, ds, gp, gs, real, z, mix, depth, alpha, src):
+    """One critic iteration of the oracle in fp64 that also records, for every LeakyReLU of its three critic passes
+    (reals, fakes, interpolates; reference losses.py:76-79, 113) in call order, which branch each output took.
+    Returns (aux of the loss, parameter tensors, gradients per term {'real', 'fake', 'gp'}, masks)."""
+    tape = []
+    orig_forward, orig_lrelu = O.discriminator_forward, O.leaky_relu
+
+    def taped_lrelu(x, slope):
+        tape.append(torch.where(x.detach() > 0, 1.0, -1.0).float())
+        return orig_lrelu(x, slope)
+
+    def taped_forward(*a, **k):  # (the generator's activations are not recorded)
+        O.leaky_relu = taped_lrelu
+        try:
+            return orig_forward(*a, **k)
+        finally:
+            O.leaky_relu = orig_lrelu
+
+    cast = lambda prm: {k: v.detach().double().requires_grad_(True) for k, v in prm.items()}
+    dpc, gpc = cast(dp), cast(gp)
+    O.discriminator_forward = taped_forward
+    try:
+        loss, aux = O.d_loss_wgan_gp(dpc, ds, gpc, gs, real.double(), z.double(), depth, alpha, O.NetConfig(),
+                                     mix.double(), src, src)
+    finally:
+        O.discriminator_forward = orig_forward
+    params = list(dpc.values())
+    t_real = -aux["d_real"].mean() + (aux["d_real"] ** 2).mean() * 1e-3
+    t_fake = aux["d_fake"].mean()
+    t_gp = ((aux["gp_grad"].norm(p=2, dim=1) - 1.0) ** 2).mean() * 10.0  # (not loss - the others: no cancellation residue)
+    assert abs(float(t_real + t_fake + t_gp) - float(loss)) < 1e-12 * max(1.0, abs(float(loss)))
+    terms = {name: torch.autograd.grad(t, params, allow_unused=True, retain_graph=True)
+             for name, t in (("real", t_real), ("fake", t_fake), ("gp", t_gp))}
+    return loss.detach(), aux, terms, tape
+
+
+BRANCH_TOL = 1e-4
+
+
+def critic_terms_under_reference_branches(dev, depth, alpha, B, seed):
+    """One critic iteration on the device with every LeakyReLU of the critic taking the branch the fp64 oracle took,
+    against that oracle run: (relative loss deviation, deviation of the penalty's input gradient, {term.tensor:
+    deviation of the term's gradient relative to its own norm}).  Weight gradients are taken the trainers' way
+    (deposited directly, in groups), GDrop multipliers follow the reference's host stream on both sides, and the
+    critic sees the oracle's fakes (rounded to float32), so both sides evaluate the same piecewise-linear function
+    on the same inputs."""
+    from eeggan_amd import config, layers, losses, ops
+    from oracle import ref_cpu as O
+    g, d = _build(dev, depth, alpha, 5)
+    gp, gs = oracle_params(g)
+    dp, ds = oracle_params(d)
+    T = config.seq_len(depth)
+    rng = np.random.default_rng(seed)
+    real = torch.from_numpy(O.synthetic_eeg(B, 5, T, rng))
+    gen = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, 256, generator=gen)
+    mix = torch.rand(B, 1, 1, generator=gen)
+    np.random.seed(seed)
+    loss_ref, aux, terms_ref, tape = _taped_oracle_critic_iteration(O, dp, ds, gp, gs, real, z, mix, depth, alpha,
+                                                                    O.DropSource("numpy"))
+    g, d = g.to(dev), d.to(dev)
+    g.depth = d.depth = depth
+    g.alpha = d.alpha = alpha
+    # the critic's three passes in the reference's order; host RNG order as in the loss: D(real), G(z), D(fake), D(x_hat)
+    np.random.seed(seed)
+    reald = real.to(dev)
+    with layers.forced_masks([m.to(dev) for m in tape]) as forced:
+        d.zero_grad()
+        d_real = d({"x": reald})[0]
+        with torch.no_grad():
+            g({"z": z.to(dev)})  # (consumes the generator's draws of the host stream)
+        faked = aux["fake"].float().to(dev)
+        d_fake = d({"x": faked})[0]
+        x_hat = ops.mix_batch_raw(reald, faked, mix.to(dev)).requires_grad_(True)
+        pred = d({"x": x_hat})[0]
+        gg = losses.calc_grad(x_hat, pred).view(B, -1)
+        assert next(forced.masks, None) is None, "the critic made fewer LeakyReLU calls than the oracle"
+        loss = ops.wgan_gp_d_loss(d_real, d_fake, gg, 1e-3, 10.0, 1.0)
+        heads = torch.autograd.grad(loss, [d_real, d_fake, gg], retain_graph=True)
+        params = list(d.parameters())
+        got = {}
+        for term, o, head in (("real", d_real, heads[0]), ("fake", d_fake, heads[1]), ("gp", gg, heads[2])):
+            d.zero_grad()
+            with ops.direct_weight_grads():
+                torch.autograd.backward(o, head, retain_graph=True)
+            got[term] = [None if p.grad is None else p.grad.clone() for p in params]
+    errs = {}
+    for term in ("real", "fake", "gp"):
+        for (k, _), mine, ref in zip(d.named_parameters(), got[term], terms_ref[term]):
+            if ref is None or float(ref.norm()) == 0.0:
+                assert mine is None or float(mine.abs().max()) == 0.0, f"{term}.{k}: the oracle has no gradient here"
+                continue
+            assert mine is not None, f"{term}.{k}: missing gradient"
+            errs[f"{term}.{k}"] = rel(mine, ref)
+    loss_err = abs(float(loss) - float(loss_ref)) / max(1.0, abs(float(loss_ref)))
+    return loss_err, rel(gg, aux["gp_grad"]), errs
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_headline_configuration_under_reference_branches(dev, alpha):
+    """The configuration the metric is quoted on (final stage, T = 1920, 32 samples; alpha 1 and mid-transition), one
+    critic iteration with every LeakyReLU of the critic taking the branch the fp64 oracle took (reference
+    layers.py:196-200 inside losses.py:73-120).  The critic is then the oracle's piecewise-linear function on both
+    sides -- no branch can flip under rounding -- and the gradient of EVERY term (reals, fakes, penalty: the double
+    backward) of EVERY tensor must agree to 1e-4 of that term's own norm, with no noise or conditioning allowance:
+    the test a systematic error of a kernel cannot pass."""
+    loss_err, gp_err, errs = critic_terms_under_reference_branches(dev, 7, alpha, 32, 1373)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print(f"under the oracle's LeakyReLU branches (alpha {alpha}): loss {loss_err:.1e}, penalty input gradient "
+          f"{gp_err:.1e}, worst of {len(errs)} term gradients {worst[1]:.2e} ({worst[0]})")
+    assert loss_err < 1e-5 and gp_err < BRANCH_TOL
+    for k, e in errs.items():
+        assert e < BRANCH_TOL, f"critic term gradient {k}: differs by {e:.3e} under the oracle's branches"
 
 
 @pytest.mark.parametrize("alpha", [1.0, 0.5])
@@ -447,7 +617,7 @@ def test_benchmarked_launch_path_against_oracle(dev, alpha):
     _, last32 = _oracle_d_grads(O, dp, ds, gp, gs, reals[-1], zs[-1], mix, depth, alpha, torch.float32)
     loss_ref = float(per_iter[-1][0])
     assert abs(d_loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (d_loss, loss_ref)
-    worst = (0.0, "")
+    worst, log = (0.0, ""), _GateLog()
     for i, (k, p) in enumerate(d.named_parameters()):
         gr = per_iter[-1][1][i]
         if gr is None:
@@ -456,7 +626,7 @@ def test_benchmarked_launch_path_against_oracle(dev, alpha):
         m, v = d_mom[i]
         assert float(opt_d.state[p]["step"]) == repeats * (1 + COND_TRIALS), k
         cd = d_cond[i] / scales[i]
-        worst = _oracle_gate(f"D.{k}", m, gr, last32[i], worst, scales[i], cd)
+        worst = _oracle_gate(f"D.{k}", m, gr, last32[i], worst, scales[i], cd, log)
         # second moment: squares of the five gradients; a deviation e of a gradient (on the scale above)
         # moves it by 2 e |g| scale, so it is held to 4x the gradient's tolerance on the squared scale
         v_ref = sum(0.01 * 0.99 ** (repeats - 1 - j) * per_iter[j][1][i] ** 2 for j in range(repeats))
@@ -482,7 +652,8 @@ def test_benchmarked_launch_path_against_oracle(dev, alpha):
             continue
         assert float(opt_g.state[p]["step"]) == 1.0 + COND_TRIALS, k
         worst = _oracle_gate(f"G.{k}", g_mom[i][0], gg64[i], gg32[i], worst, None,
-                             g_cond[i] / max(float(gg64[i].norm()), 1e-300))
+                             g_cond[i] / max(float(gg64[i].norm()), 1e-300), log, family="generator")
+    log.report(f"benchmarked path, alpha {alpha:g}")
     print(f"benchmarked path, alpha {alpha:g}: d_loss {d_loss:.6f} (oracle {loss_ref:.6f}), g_loss {g_loss:.6f} "
           f"(oracle {float(gl64):.6f}); worst gradient deviation = {worst[0]:.2f} x the oracle's fp32-vs-fp64 "
           f"distance ({worst[1]})")

@@ -575,6 +575,35 @@ def test_minibatch_stddev_orders(dev, B):
     assert float(err) < 5 * TOL
 
 
+@pytest.mark.parametrize("T,stride,segments", [(32, 16, 1), (32, 6, 1), (48, 32, 2), (40, 8, 2)])
+def test_minibatch_stddev_temporal_windows(dev, T, stride, segments):
+    """Statistics per temporal window of ``stride`` steps (reference layers.py:72, 81-89; a last window shorter
+    than the others when the stride does not divide the signal), to second order, alone and on stacked minibatches."""
+    ops = _ops()
+    O = _oracle()
+    g = torch.Generator().manual_seed(T + stride)
+    B, C = 8, 24
+    x = torch.randn(segments * B, C, T, generator=g)
+    x64 = x.double().requires_grad_(True)
+    yref = torch.cat([O.minibatch_stddev(part, 4, stride) for part in x64.chunk(segments)])
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.minibatch_stddev(xd, 4, segments, stride)
+    assert rel(y, yref) < TOL
+    gy = torch.randn(segments * B, C + 1, T, generator=g)
+    gy64, gyd = gy.double().requires_grad_(True), gy.to(dev).requires_grad_(True)
+    (gx_ref,) = torch.autograd.grad(yref, x64, gy64, create_graph=True)
+    (gx,) = torch.autograd.grad(y, xd, gyd, create_graph=True)
+    assert rel(gx, gx_ref) < TOL
+    v = torch.randn(segments * B, C, T, generator=g)
+    ggy_ref, gxx_ref = torch.autograd.grad(gx_ref, [gy64, x64], v.double())
+    ggy, gxx = torch.autograd.grad(gx, [gyd, xd], v.to(dev))
+    assert rel(ggy, ggy_ref) < TOL
+    assert float((gxx.double().cpu() - gxx_ref).norm() / (gxx_ref.norm() + 1e-3 * v.double().norm())) < 5 * TOL
+    from eeggan_amd._lib import EegganError, call
+    with pytest.raises(EegganError):  # a window that leaves the signal is refused on the host
+        call("eeggan_mbstd_bwd_window", xd.data_ptr(), gyd.data_ptr(), gx.data_ptr(), B, C, T, T - 2, 4, 4, 0)
+
+
 def test_losses(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(3)

@@ -47,6 +47,8 @@ CASES = {
     "conv_only": dict(generator=dict(conv_only=True), discriminator=dict(conv_only=True)),
     "d_batch_norm": dict(discriminator=dict(act_norm="batch")),
     "d_pixel_norm": dict(discriminator=dict(act_norm="pixel")),
+    "temporal_groups": dict(discriminator=dict(temporal_groups_per_window=2)),
+    "temporal_groups_ragged": dict(discriminator=dict(temporal_groups_per_window=5, group_size=2)),
 }
 
 
@@ -72,7 +74,7 @@ def _oracle_config(case):
     for src, keys in ((case.get("shared", {}), ("residual", "act_alpha", "deep", "self_attention_layers")),
                       (case.get("generator", {}), ("rgb_generation_mode", "no_tanh", "normalize_latents", "z_to_bn", "split_z",
                                                    "to_rgb_mode")),
-                      (case.get("discriminator", {}), ("input_to_all_layers", "group_size"))):
+                      (case.get("discriminator", {}), ("input_to_all_layers", "group_size", "temporal_groups_per_window"))):
         kw.update({k: src[k] for k in keys if k in src})
     if "act_norm" in case.get("generator", {}):
         kw["g_act_norm"] = case["generator"]["act_norm"]

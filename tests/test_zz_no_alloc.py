@@ -1,6 +1,7 @@
 """The entry point that allocates nothing (``eeggan_mbstd_fwd_static``: partial sums in a buffer built into
 the library) against ``eeggan_mbstd_fwd`` with a caller-provided workspace, through the C ABI: bit-exact, on
-two calls in a row, the second with a smaller input (the shared buffer keeps the first call's contents)."""
+two calls in a row, the second with a smaller input (the shared buffer keeps the first call's contents); and
+against the CPU oracle's MinibatchStddev (reference layers.py:67-90) in float64 at 1e-5."""
 import ctypes
 
 import pytest
@@ -25,6 +26,8 @@ def _both(lib, x, group):
 
 def test_static_scratch_entry_point_matches_workspace_entry_point(dev):
     from eeggan_amd import _lib
+    from helpers import rel
+    from oracle import ref_cpu as O
     lib = _lib.load()
     gen = torch.Generator(device=dev).manual_seed(5)
     for B, C, T in ((32, 256, 32), (8, 64, 32)):  # the second call is smaller than the first
@@ -32,6 +35,8 @@ def test_static_scratch_entry_point_matches_workspace_entry_point(dev):
         ref, got = _both(lib, x, 4)
         assert torch.isfinite(ref).all()
         assert torch.equal(ref, got), (B, C, T)
+        want = O.minibatch_stddev(x.double().cpu(), 4, T)
+        assert rel(got, want) < 1e-5, (B, C, T, rel(got, want))
 
 
 def test_static_scratch_entry_point_rejects_oversized_inputs(dev):

@@ -66,6 +66,10 @@ CASES = {
     # (depth 2 at alpha 1 was tried first: one pre-activation of the critic lies within 5e-7 of zero there, and the
     # fp32 rounding of the fakes flips its LeakyReLU -- 5e-3 on that sample's input gradient in pure fp64 arithmetic)
     "d_pixel_norm": dict(discriminator=dict(act_norm="pixel"), depth=3, alpha=0.7),
+    # MinibatchStddev over several temporal windows (layers.py:72, 81-89): two windows of 16 steps, and 32 // 5 = 6
+    # steps per window, i.e. five windows of 6 and the remainder of 2
+    "temporal_groups": dict(discriminator=dict(temporal_groups_per_window=2), depth=2, alpha=1.0),
+    "temporal_groups_ragged": dict(discriminator=dict(temporal_groups_per_window=5, group_size=2), depth=1, alpha=0.5),
 }
 
 
@@ -89,7 +93,7 @@ def oracle_config(case):
     kw["g_conv_only"], kw["d_conv_only"] = bool(ge.get("conv_only")), bool(di.get("conv_only"))
     if "act_norm" in di:
         kw["d_act_norm"] = di["act_norm"]
-    for k in ("input_to_all_layers", "group_size"):
+    for k in ("input_to_all_layers", "group_size", "temporal_groups_per_window"):
         if k in di:
             kw[k] = di[k]
     return O.NetConfig(**kw)
