@@ -425,7 +425,7 @@ class GraphedTrainer(Trainer):
                 real = cudize(next(self.dataiter))["x"]
                 if real.shape != self._real.shape:
                     raise RuntimeError("GraphedTrainer: the batch shape changed inside a step")
-            self.cur_nimg += n
+            self._count_reals(n)
             self._real.copy_(real)
             if fakes is not None:  # (the iteration's latents went into the fakes already)
                 self._fake.copy_(fakes[i * n:(i + 1) * n])

@@ -112,6 +112,12 @@ class Trainer(object):
     def _next_latents(self):
         return cudize(next(self.random_latents_generator))
 
+    def _count_reals(self, local_batch: int) -> None:
+        """The progress counter follows the reals shown to the WHOLE job: with a data-parallel ``grad_sync`` every
+        rank holds ``local_batch`` of a global batch of ``world`` times as many, and the schedule the plugins read
+        (depth, fade-in, ticks: reference plugins.py:78-119, trainer.py:62-77) is defined in reals."""
+        self.cur_nimg += local_batch * int(getattr(self.grad_sync, "world", 1) or 1)
+
     def train(self):
         """5 x (critic loss, backward, Adam) then generator loss, backward, Adam: reference trainer.py:79-96."""
         if self.lr_scheduler_g is not None:
@@ -121,7 +127,7 @@ class Trainer(object):
             if self.lr_scheduler_d is not None:
                 self.lr_scheduler_d.step(self.cur_nimg)
             reals = cudize(next(self.dataiter))
-            self.cur_nimg += reals["x"].size(0)
+            self._count_reals(reals["x"].size(0))
             d_loss = self.d_loss(self.discriminator, self.generator, reals, latents)
             self._step(d_loss, self.optimizer_d, self.discriminator)
             latents = self._next_latents()

@@ -1055,6 +1055,168 @@ def test_stacked_critic_pass_equals_sequential(dev):
             assert e < 2e-2, f"{k}: {what} pass differs by {e:.2e} of the real term's scale"
 
 
+def _progression_run(dev, lr, shard=None, sync_factory=None, jitter=0.0):
+    """The graph trainer driven by the reference's DepthManager (plugins.py:28-119) through three stable steps at
+    depth 0, two steps of fade-in (alpha 1/3, 2/3) and two stable steps at depth 1, on global batches of 16 reals
+    (noise off, fixed mixing factors, seeded data).  ``shard`` = (rank, world): this process takes its share of
+    every batch and sums gradients through ``sync_factory()``.  Returns the final weights and moments (as
+    ``_two_steps`` does) plus, per step, (depth, alpha, number of critic tensors in this step's gradient buckets)."""
+    from eeggan_amd import config
+    from eeggan_amd.graphs import GraphedTrainer
+    from eeggan_amd.layers import GDropLayer
+    from eeggan_amd.optim import Adam
+    from eeggan_amd.parallel import shard_batch
+    from eeggan_amd.plugins import DepthManager, Plugin
+    B = 16
+    own = (lambda t: shard_batch(t, shard[0], shard[1]).contiguous()) if shard is not None else (lambda t: t)
+
+    class SmallStages(DepthManager):
+        minibatch_override = {0: B, 1: B}
+        tick_kimg_override = training_kimg_override = transition_kimg_override = {}
+
+    class Dataset:
+        model_depth, alpha = 0, 1.0
+
+    g, d = config.build_models(9)
+    g, d = g.to(dev), d.to(dev)
+    for m in list(g.modules()) + list(d.modules()):
+        if isinstance(m, GDropLayer):
+            m.strength = 0
+    ds = Dataset()
+    mix = own(torch.rand(B, 1, 1, generator=torch.Generator().manual_seed(21))).to(dev)
+
+    def loader(minibatch):  # (a new loader per stage, as the reference's create_dataloader_fun: seeded by the stage)
+        depth = ds.model_depth
+        gen, jgen = torch.Generator().manual_seed(100 + depth), torch.Generator().manual_seed(300 + depth)
+        while True:
+            r = torch.randn(minibatch, 5, config.seq_len(depth), generator=gen)
+            if jitter:
+                r = r * (1 + jitter * torch.randn(r.shape, generator=jgen))
+            yield {"x": own(r).to(dev)}
+
+    def latents(minibatch):
+        gen = torch.Generator().manual_seed(200 + ds.model_depth)
+        while True:
+            yield {"z": own(torch.randn(minibatch, 256, generator=gen)).to(dev)}
+
+    opts = []
+
+    def optimizers(stage_lr):  # (the learning rate under test replaces the stage's; the reset per stage stays)
+        opts[:] = [Adam(g.parameters(), lr, **config.ADAM), Adam(d.parameters(), lr, **config.ADAM)]
+        return opts[0], opts[1], None, None
+
+    class Watch(Plugin):
+        def __init__(self):
+            super().__init__([(1, "iteration")])
+            self.seen = []
+
+        def register(self, trainer):
+            self.trainer = trainer
+
+        def iteration(self, *args):  # (runs BEFORE the depth manager's hook of the same step: registered first)
+            tr = self.trainer
+            sync = tr.grad_sync
+            tensors = None if sync is None else sum(len(b.params) for (mod, _), b in sync.buckets.items() if mod == id(d))
+            self.seen.append((tr.generator.depth, round(float(tr.generator.alpha), 4), tensors))
+
+    d_loss_fn, g_loss_fn = config.loss_closures()
+    tr = GraphedTrainer(d, g, lambda dis, ge, r, z, **kw: d_loss_fn(dis, ge, r, z, mixing=mix, **kw), g_loss_fn, ds,
+                        None, 0, None, None, tick_kimg_default=1.0)
+    if sync_factory is not None:
+        tr.grad_sync = sync_factory()
+    watch = Watch()
+    tr.register_plugin(watch)
+    tr.register_plugin(SmallStages(loader, latents, 1, 1.0, optimizers, 0.001, lod_training_kimg=0.16,
+                                   lod_transition_kimg=0.24))
+    tr.run(total_kimg=0.56)
+    torch.cuda.synchronize()
+    out = {}
+    for tag, net, opt in (("G", g, opts[0]), ("D", d, opts[1])):
+        for k, p in net.named_parameters():
+            out[f"{tag}.{k}"] = p.detach().clone()
+            if p in opt.state:
+                st = opt.state[p]
+                out[f"{tag}.{k}.m"], out[f"{tag}.{k}.v"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+                out[f"{tag}.{k}.step"] = st["step"].clone()
+    return out, watch.seen
+
+
+def _progression_worker(rank, world, port, out):
+    """One rank of ``_progression_run`` with DataParallelStep over gloo (both ranks share the one GPU; the buckets
+    cross to host memory around the collective)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import test_e2e_gpu as T
+    from eeggan_amd import layers
+    from eeggan_amd.parallel import DataParallelStep
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    layers.set_drop_mode("device")
+    res = []
+    for lr in (0.0, 0.002):
+        state, seen = T._progression_run(dev, lr, shard=(rank, world), sync_factory=DataParallelStep)
+        res.append(({k: v.cpu().numpy() for k, v in state.items()}, seen))
+    if rank == 0:
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_through_a_depth_change(dev):
+    """Two ranks (DataParallelStep under the graph trainer) through the progressive schedule: a stable stage, the
+    fade-in of the next one and that stage stable.  The set of critic tensors that receive gradients changes at
+    both borders (8 -> 14 -> 12: the fade-in adds the lower stage's from_rgb, reference network.py:533-540), so the
+    gradient buckets must be rebuilt twice; the optimizers are replaced at the depth change (plugins.py:106-108);
+    the schedule must follow the GLOBAL count of reals on every rank.  The two-rank trajectory must be the
+    one-process trajectory on the global batches: the depth manager's sequence exactly, Adam's moments of the last
+    stage with lr = 0 up to the measured rounding response, the weight displacements with lr > 0 to 25 %."""
+    import socket
+    import torch.multiprocessing as mp
+    from eeggan_amd import layers
+    layers.set_drop_mode("device")
+    try:
+        (frozen, seen), (live, _) = _progression_run(dev, 0.0), _progression_run(dev, 0.002)
+        again, _ = _progression_run(dev, 0.0, jitter=1e-6)
+    finally:
+        layers.set_drop_mode("numpy")
+    want = [(0, 1.0), (0, 1.0), (0, 1.0), (1, 0.3333), (1, 0.6667), (1, 1.0), (1, 1.0)]
+    assert [s[:2] for s in seen] == want, seen
+    noise = max(float((a - again[k]).abs().max()) / max(float(a.abs().max()), 1e-30)
+                for k, a in frozen.items() if k.endswith((".m", ".v")))
+    gate = max(1e-5, min(NOISE_FACTOR * noise, COND_CAP))
+    print(f"rounding noise of the last stage's moments (worst tensor): {noise:.2e} -> gate {gate:.2e}")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_progression_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get() if _wait_for(procs, out, 300) else None
+    for p in procs:
+        p.join(60)
+        if p.is_alive():
+            p.kill()
+    assert res is not None and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    (frozen2, seen2), (live2, seen2_live) = res
+    # every rank followed the one-process schedule (it counts the global batch) ...
+    assert [s[:2] for s in seen2] == want and [s[:2] for s in seen2_live] == want, (seen2, seen2_live)
+    # ... and its buckets were rebuilt at both borders: 8 critic tensors with gradients at depth 0, 14 in the
+    # fade-in, 12 at depth 1
+    assert [s[2] for s in seen2] == [8, 8, 8, 14, 14, 12, 12], [s[2] for s in seen2]
+    ranks = tuple({k: torch.from_numpy(v).to(dev) for k, v in r.items()} for r in (frozen2, live2))
+    worst = max(float((a - ranks[0][k]).abs().max()) / max(float(a.abs().max()), 1e-30)
+                for k, a in frozen.items() if k.endswith((".m", ".v")))
+    print(f"two ranks through the depth change against the global batch, moments (worst tensor): {worst:.2e}")
+    _same_trajectory((frozen, live), ranks, "two ranks through a depth change", moment_tol=gate)
+
+
 def test_progressive_schedule_with_graphs(dev):
     """DepthManager (the reference's plugins.py:78-119 schedule) driving the graph trainer through a
     stable stage, a fade-in and the next stable stage: depth/alpha/optimizers/minibatch change under

@@ -92,6 +92,22 @@ def test_depth_manager_schedule():
     assert tr2.stats["depth"] == 7 and tr2.stats["alpha"]["val"] == 1.0 and dm2.stage_settings(4)[0] == 48
 
 
+def test_progress_counts_the_global_batch_under_data_parallelism():
+    """``cur_nimg`` (what the depth manager and the tick logic read, reference trainer.py:62-77, plugins.py:78-97)
+    advances by the reals shown to the whole job: a rank of a two-rank job that holds 8 of 16 counts 16."""
+    from eeggan_amd.trainer import Trainer
+
+    class _Sync:
+        world = 2
+
+    tr = Trainer(None, None, None, None, None, None, 100, None, None)
+    tr._count_reals(8)
+    assert tr.cur_nimg == 108
+    tr.grad_sync = _Sync()
+    tr._count_reals(8)
+    assert tr.cur_nimg == 124
+
+
 def test_resample_tables_match_interpolate_then_pool():
     from eeggan_amd.resample_tables import build_tables
     up, dn = [4, 2, 2, 3, 4, 5, 3], [1, 1, 1, 2, 3, 4, 2]
