@@ -494,10 +494,34 @@ class GeneralConv(nn.Module):
         pointwise = self.conv.net[1] if self.separable else self.conv
         return self.drop.sample(x.shape[0], pointwise.conv.out_channels, x.device)
 
+    def _with_conv_noise(self, x, c, y, z, conv_noise):
+        """conv -> * noise[b, ch] -> (norm) -> activation -> (PixelNorm) -> (GDrop) piece by piece (reference
+        layers.py:207-213 with ``conv_noise``): the multiplier sits between the conv and the activation, and its
+        gradient needs the conv's own output, so this form does not run as the fused layer.  First-order
+        differentiable (the generator's layers)."""
+        w, b, s = c.weight(), c.conv.bias, c.scale
+        kind = c.kind(x)
+        if kind == "tail" or self.second_order:
+            raise NotImplementedError("per-channel conv noise in the critic's layers")
+        xin = x.squeeze(2) if kind == "head" else x
+        lin = ops.g_layer(xin, w, b, None, s, 0.0, mode="linear", kind=kind, flip=c._flip)
+        h = ops.row_scale(lin, conv_noise)
+        slope = float(max(self.act_alpha, 0.0))
+        mult = self._multipliers(x)
+        if self.act_norm == "batch":
+            return self.norm.apply_with(h, z, mult, slope if self.act_alpha >= 0 else 1.0, y=y)
+        if self.act_alpha >= 0:
+            h = ops.lrelu_drop(h, None, slope)
+        if self.act_norm == "pixel":
+            h = ops.pixel_norm(h)
+        return h if mult is None else ops.lrelu_drop(h, mult, 1.0)
+
     def forward(self, x, y=None, z=None, conv_noise=None, _tanh_scale=None):
-        if conv_noise is not None:
-            raise NotImplementedError("per-channel conv noise is not supported")
         c = self.conv
+        if conv_noise is not None:
+            if self.separable or _tanh_scale is not None:
+                raise NotImplementedError("per-channel conv noise on a separable or to_rgb layer")
+            return self._with_conv_noise(x, c, y, z, conv_noise)
         if self.separable:
             # the depthwise half (which also does the full-length layers' change of length), then the 1x1 half as an
             # ordinary same-padded layer with this layer's epilogue

@@ -22,9 +22,10 @@ either a tensor or the dict the reference's losses pass (``{'z': ...}`` / ``{'x'
 from __future__ import annotations
 
 import numpy as np
+import torch
 from torch import nn
 
-from . import ops
+from . import layers, ops
 from ._lib import ACT_NONE
 from .layers import ConcatResidual, ConditionalBatchNorm, GeneralConv, MinibatchStddev, PassChannelResidual, ScaledTanh, SelfAttention
 from .utils import pixel_norm, resample_signal
@@ -60,17 +61,23 @@ class GBlock(nn.Module):
     def __init__(self, ch_in, ch_out, ch_rgb, k_size=3, initial_kernel_size=None, is_residual=False, no_tanh=False,
                  deep=False, per_channel_noise=False, to_rgb_mode="pggan", **layer_settings):
         super().__init__()
-        _require(not per_channel_noise, "GBlock(per_channel_noise)")
         first = initial_kernel_size is not None
         hidden = max((ch_in // 4) if deep else ch_out, 4)  # (network.py:157-169: four layers through a bottleneck)
         self.convs = nn.ModuleList([
             GeneralConv(ch_in, hidden, kernel_size=initial_kernel_size if first else k_size,
                         pad=initial_kernel_size - 1 if first else None, **layer_settings),
             GeneralConv(hidden, hidden if deep else ch_out, kernel_size=k_size, **layer_settings)])
+        # (network.py:162-172) one learned weight per layer and channel, zero at construction, for the noise that
+        # multiplies the layer's conv output; registered in the reference's order (state-dict keys ``noises.i``)
+        widths = [hidden, hidden if deep else ch_out] + ([hidden, ch_out] if deep else [])
+        self.noises = nn.ParameterList([nn.Parameter(torch.zeros(1, widths[0], 1)),
+                                        nn.Parameter(torch.zeros(1, widths[1], 1))]) if per_channel_noise else None
         if deep:
             self.convs.append(GeneralConv(hidden, hidden, kernel_size=k_size, **layer_settings))
             self.convs.append(GeneralConv(hidden, ch_out, kernel_size=k_size, **layer_settings))
-        self.noises = None
+            if per_channel_noise:
+                self.noises.append(nn.Parameter(torch.zeros(1, widths[2], 1)))
+                self.noises.append(nn.Parameter(torch.zeros(1, widths[3], 1)))
         rgb_settings = {k: layer_settings[k] for k in ("equalized", "spectral", "init")}
         if to_rgb_mode == "pggan":  # (network.py:175-187)
             to_rgb = GeneralConv(ch_out, ch_rgb, kernel_size=1, act_alpha=-1, **rgb_settings)
@@ -98,10 +105,25 @@ class GBlock(nn.Module):
                                                                               **rgb_settings)
         self.deep = deep
 
+    @staticmethod
+    def get_per_channel_noise(noise_weight, batch_size):
+        """N(0, 1)[B, C, 1] * weight[1, C, 1] (network.py:203-205), or None without a weight.  The draw follows the
+        layers' noise mode: from torch's host generator like the reference's (so equal seeds give equal draws), or
+        on the device (no host round trip; graph-capturable).  The product is two tiny tensors: torch's own kernel."""
+        if noise_weight is None:
+            return None
+        shape = (batch_size,) + tuple(noise_weight.shape[1:])
+        if layers.get_drop_mode() == "numpy":
+            draw = torch.randn(shape).to(noise_weight.device)
+        else:
+            draw = torch.randn(shape, device=noise_weight.device)
+        return draw * noise_weight
+
     def forward(self, x, y=None, z=None, last=False):
         h = x
-        for conv in self.convs:
-            h = conv(h, y=y, z=z)
+        for i, conv in enumerate(self.convs):
+            weight = self.noises[i] if self.noises is not None else None
+            h = conv(h, y=y, z=z, conv_noise=self.get_per_channel_noise(weight, x.size(0)))
         if self.deep:
             h = self.residual(h, x)
         elif self.residual is not None:
@@ -120,7 +142,6 @@ class Generator(nn.Module):
         _require(num_classes == 0 or act_norm == "batch", "class conditioning without batch norm layers")
         _require(not conv_only or not (z_to_bn or split_z), "conv_only with z_to_bn / split_z")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
-        _require(not per_channel_noise, "per_channel_noise")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
             raise ValueError("invalid rgb_generation_mode: {}".format(rgb_generation_mode))
         _require(act_norm in (None, "pixel", "batch"), f"act_norm={act_norm!r}")

@@ -1203,6 +1203,16 @@ def batch_norm_twice(c, gamma, beta, run_mean, run_var, eps, momentum, train):
     return _ChanAffine.apply(c, scale, (beta - run_mean * scale).contiguous(), (B, C, T))
 
 
+def row_scale(x, n):
+    """x[b, ch, t] * n[b, ch] (``n`` given as [B, C] or [B, C, 1]), differentiable in both (any order): the
+    per-channel affine op on the tensor read as one sample of B * C channels."""
+    B, C, T = x.shape
+    if n.numel() != B * C:
+        raise RuntimeError(f"row_scale: {tuple(n.shape)} multipliers for a tensor {tuple(x.shape)}")
+    flat = _ChanAffine.apply(x.reshape(1, B * C, T), n.reshape(B * C).contiguous(), None, (1, B * C, T))
+    return flat.reshape(B, C, T)
+
+
 def lrelu_drop(o, drop, slope):
     """drop[b, ch] * lrelu_slope(o), differentiable to any order (piecewise linear: the mask is a constant)."""
     return _MaskMul.apply(o, o.detach(), drop, float(slope))

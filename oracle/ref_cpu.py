@@ -243,8 +243,8 @@ def conditional_batch_norm(x, params, scales, prefix: str, z=None, y=None):
 
 
 def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None, drop=0.0,
-                 src: Optional[DropSource] = None, z=None, y=None):
-    """layers.py:207-213 for the default options: conv -> LeakyReLU ->
+                 src: Optional[DropSource] = None, z=None, y=None, conv_noise=None):
+    """layers.py:207-213 for the default options: conv -> (* conv_noise) -> LeakyReLU ->
     (PixelNorm) -> (GDrop).  ``act_alpha < 0`` means linear."""
     if has_layer(params, f"{path}.conv.net.0.conv"):
         # separable layer (layers.py:137-147): a depthwise conv with its own scale and bias and the layer's padding,
@@ -261,6 +261,8 @@ def general_conv(x, params, scales, path, *, pad=None, act_alpha=0.2, norm=None,
         k = w.shape[2]
         pad = (k - 1) // 2 if pad is None else pad
         h = equalized_conv1d(x, w, b, scales[path], pad)
+    if conv_noise is not None:  # layers.py:209-210
+        h = h * conv_noise
     if norm == "batch":  # layers.py:211-212: between conv and activation
         h = conditional_batch_norm(h, params, scales, f"{path}.norm", z, y)
     if act_alpha >= 0:
@@ -369,12 +371,22 @@ def g_block(params, scales, prefix: str, h, cfg: NetConfig, src: "DropSource", f
     ``last`` appends to_rgb = linear 1x1 conv + ScaledTanh (network.py:173-176, 188-191; layers.py:17-23)."""
     ls = dict(act_alpha=cfg.act_alpha, norm=cfg.g_act_norm, drop=cfg.g_dropout, src=src, z=z, y=y)
     x = h
+
+    def noise(i):
+        """network.py:203-208: N(0, 1)[B, C, 1] from torch's global (host) generator times the learned weight
+        ``noises.i`` [1, C, 1], drawn right before layer i runs; None without ``per_channel_noise``."""
+        weight = params.get(f"{prefix}.noises.{i}")
+        if weight is None:
+            return None
+        return torch.randn(x.shape[0], *weight.shape[1:]).to(weight.dtype) * weight
+
     first = first and not cfg.g_conv_only  # (network.py:35, 303: a fully convolutional generator has no full-length layer)
-    h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None, **ls)
-    h = general_conv(h, params, scales, f"{prefix}.convs.1", **ls)
+    h = general_conv(h, params, scales, f"{prefix}.convs.0", pad=cfg.initial_kernel_size - 1 if first else None,
+                     conv_noise=noise(0), **ls)
+    h = general_conv(h, params, scales, f"{prefix}.convs.1", conv_noise=noise(1), **ls)
     if cfg.deep:  # network.py:167-169, 213-216; PassChannelResidual (layers.py:216-223): the input's first channels
-        h = general_conv(h, params, scales, f"{prefix}.convs.2", **ls)
-        h = general_conv(h, params, scales, f"{prefix}.convs.3", **ls)
+        h = general_conv(h, params, scales, f"{prefix}.convs.2", conv_noise=noise(2), **ls)
+        h = general_conv(h, params, scales, f"{prefix}.convs.3", conv_noise=noise(3), **ls)
         h = x[:, :h.shape[1]] + h
     elif cfg.residual and not first:  # network.py:195-199, 217-218
         h = h + _skip(params, scales, f"{prefix}.residual", x)

@@ -37,8 +37,8 @@ def test_unsupported_options_raise():
     from eeggan_amd import config
     from eeggan_amd.network import Discriminator, Generator
     kw = config.shared_model_kwargs()
-    with pytest.raises(NotImplementedError):
-        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
+    noisy = Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
+    assert "blocks.6.noises.1" in noisy.state_dict() and float(noisy.block0.noises[0].abs().sum()) == 0.0
     with pytest.raises(NotImplementedError):
         Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True, "split_z": True})
     with pytest.raises(NotImplementedError):

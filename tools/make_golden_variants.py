@@ -68,6 +68,11 @@ CASES = {
     "d_pixel_norm": dict(discriminator=dict(act_norm="pixel"), depth=3, alpha=0.7),
     # MinibatchStddev over several temporal windows (layers.py:72, 81-89): two windows of 16 steps, and 32 // 5 = 6
     # steps per window, i.e. five windows of 6 and the remainder of 2
+    # per-channel noise on every generator layer's conv output (network.py:162-172, 203-208): the learned weights
+    # start at zero (which zeroes the layer), so they are set away from it; the draws come from torch's host generator
+    "per_channel_noise": dict(generator=dict(per_channel_noise=True), depth=2, alpha=0.6, noise_weights=True),
+    "per_channel_noise_deep": dict(shared=dict(deep=True), generator=dict(per_channel_noise=True, act_norm="batch"),
+                                   depth=1, alpha=1.0, noise_weights=True),
     "temporal_groups": dict(discriminator=dict(temporal_groups_per_window=2), depth=2, alpha=1.0),
     "temporal_groups_ragged": dict(discriminator=dict(temporal_groups_per_window=5, group_size=2), depth=1, alpha=0.5),
 }
@@ -111,7 +116,20 @@ def build_pair(case):
         assert M.scales_of(a) == M.scales_of(b), f"{nm}: equalized scales differ"
     if "gamma" in case:
         set_gamma(g_ref, d_ref, case["gamma"])
+    if case.get("noise_weights"):
+        set_noise_weights(g_ref)
     return g_ref, d_ref
+
+
+def set_noise_weights(g):
+    """The per-channel noise weights (zero at construction): 0.6 .. 1.4 along the channels, the sign alternating from
+    tensor to tensor."""
+    with torch.no_grad():
+        j = 0
+        for k, p in g.named_parameters():
+            if ".noises." in k:
+                p.copy_(torch.linspace(0.6, 1.4, p.shape[1]).view(1, -1, 1) * (1.0 if j % 2 == 0 else -1.0))
+                j += 1
 
 
 def set_gamma(g, d, value):
@@ -162,10 +180,12 @@ def main():
             ga, da = M.GAdapter(g), M.DAdapter(d)
             real, z, mix = real32.to(dtype), z32.to(dtype), mix32.to(dtype)
             np.random.seed(seed)
+            torch.manual_seed(seed + 10)  # (host draws inside the networks: per-channel noise)
             with torch.no_grad():
                 fake = g(z)[0]["x"]
                 score = d(real)[0]
             np.random.seed(seed + 1)
+            torch.manual_seed(seed + 11)
             orig = ref_losses.get_mixing_factor
             ref_losses.get_mixing_factor = lambda b: mix
             ref_losses.one, ref_losses.zero = torch.ones(batch).to(dtype), torch.zeros(batch).to(dtype)
@@ -177,6 +197,7 @@ def main():
             d_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in d.named_parameters()}
             np.random.seed(seed + 2)
             random.seed(seed + 3)
+            torch.manual_seed(seed + 12)
             g_loss = ref_losses.generator_loss(da, ga, {"x": real}, {"z": z}, loss_type, rm, fm)
             g_loss.backward()
             g_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in g.named_parameters()}
@@ -192,12 +213,14 @@ def main():
         for p in list(gp.values()) + list(dp.values()):
             p.requires_grad_(True)
         np.random.seed(seed)
+        torch.manual_seed(seed + 10)
         src = O.DropSource("numpy")
         with torch.no_grad():
             ofake = O.generator_forward(gp, gs, z, depth, alpha, cfg, src)
             oscore, _ = O.discriminator_forward(dp, ds, real, depth, alpha, cfg, src)
         assert M.rel(ofake, fake) < 1e-9 and M.rel(oscore, score) < 1e-9, (name, M.rel(ofake, fake), M.rel(oscore, score))
         np.random.seed(seed + 1)
+        torch.manual_seed(seed + 11)
         src = O.DropSource("numpy")
         ol, _ = O.d_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, mix, src, src)
         og = dict(zip(dp.keys(), torch.autograd.grad(ol, list(dp.values()), allow_unused=True)))
@@ -206,6 +229,7 @@ def main():
             assert (v is None) == (og[k] is None) and (v is None or close(og[k], v)), (name, k)
         np.random.seed(seed + 2)
         random.seed(seed + 3)
+        torch.manual_seed(seed + 12)
         src = O.DropSource("numpy")
         ol, _ = O.g_loss_any(loss_type, dp, ds, gp, gs, real, z, depth, alpha, cfg, src, src, random_multiply=rm,
                              feature_matching_lambda=fm)
