@@ -90,8 +90,9 @@ def make_trainer(dev, depth, alpha, batch, seed, world, rank, eager=False, host_
             i += 1
 
     def latents():
+        # (the latents of a whole step -- five critic iterations and the generator iteration -- in one draw)
         while True:
-            yield {"z": torch.randn(batch, config.LATENT_SIZE, device=dev, generator=gen)}
+            yield from ({"z": z} for z in torch.randn(6 * batch, config.LATENT_SIZE, device=dev, generator=gen).chunk(6))
 
     class _DS:
         model_depth, alpha = depth, 1.0

@@ -110,9 +110,14 @@ class _SplitCriticIteration:
             """Gradients that are complete once the chains are (autograd's route: the full-length layer, the
             linear layer): summed over the chains and, data-parallel, packed into a bucket of their own."""
             grads = {}
-            for _, stash in results:
+            for level, (_, stash) in enumerate(results):
+                # the first chain's tensors take the sums, in place: one launch per further chain, not one per tensor
+                # (a chain rewrites its tensors at its next replay)
+                both = [(grads[p], g) for p, g in stash if p in grads]
+                if both:
+                    ops.multi_add_([a for a, _ in both], [b for _, b in both])
                 for p, g in stash:
-                    grads[p] = g if p not in grads else grads[p] + g
+                    grads.setdefault(p, g)
             for p, g in grads.items():
                 p.grad = g
             early = list(grads)
@@ -383,6 +388,18 @@ class GraphedTrainer(Trainer):
                 net.alpha_dev.fill_(float(net.alpha))
             # (at alpha == 1 the networks take the branch without a blend and never read alpha_dev)
 
+    @staticmethod
+    def _stage(dsts, srcs):
+        """Fresh inputs into the static buffers the graphs read: one multi-tensor launch when everything is a
+        contiguous float32 device tensor (the usual case), torch's copies otherwise (another dtype, host memory)."""
+        plain = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == d.device
+                    for d, t in zip(dsts, srcs))
+        if plain:
+            ops.multi_copy_(dsts, srcs)
+        else:
+            for d, t in zip(dsts, srcs):
+                d.copy_(t)
+
     def _replay(self, parts):
         if callable(parts):
             return parts()
@@ -416,7 +433,7 @@ class GraphedTrainer(Trainer):
             self._capture(real, zs[0], key)
         fakes = None
         if self._fakes_call is not None:
-            self._zall.copy_(torch.cat(zs[:repeats]))
+            ops.multi_copy_(list(self._zall.chunk(repeats)), zs[:repeats])
             fakes = self._fakes_call()
         d_loss = None
         n = real.size(0)
@@ -426,13 +443,12 @@ class GraphedTrainer(Trainer):
                 if real.shape != self._real.shape:
                     raise RuntimeError("GraphedTrainer: the batch shape changed inside a step")
             self._count_reals(n)
-            self._real.copy_(real)
-            if fakes is not None:  # (the iteration's latents went into the fakes already)
-                self._fake.copy_(fakes[i * n:(i + 1) * n])
+            if fakes is not None:  # (the iteration's latents went into the fakes already); both inputs in one launch
+                self._stage([self._real, self._fake], [real, fakes[i * n:(i + 1) * n]])
             else:
-                self._z.copy_(zs[i])
+                self._stage([self._real, self._z], [real, zs[i]])
             d_loss = self._replay(self._d_parts)
-        self._z.copy_(zs[repeats])
+        self._stage([self._z], [zs[repeats]])
         g_loss = self._replay(self._g_parts)
         self.last_losses = (g_loss, d_loss)  # device scalars of the step's last iterations
         self.iterations += 1

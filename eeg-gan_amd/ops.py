@@ -1888,6 +1888,32 @@ def ema_update(averages, params, old_weight: float):
              _stream())
 
 
+def _pair_table(dsts, srcs, what):
+    from . import optim
+    rows = []
+    for dst, src in zip(dsts, srcs):
+        dst, src = _chk(dst, f"{what} destination"), _chk(src.detach(), f"{what} source")
+        if dst.numel() != src.numel():
+            raise RuntimeError(f"{what}: a destination and its source differ in size")
+        rows.append((dst.data_ptr(), src.data_ptr(), 0, 0, 0, dst.numel()))
+    return optim.build_table(rows), len(rows)
+
+
+def multi_copy_(dsts, srcs):
+    """dsts[k] <- srcs[k] for two lists of contiguous float32 tensors of equal sizes, in ONE launch (per 64 tensors)
+    instead of one copy kernel per tensor."""
+    table, n = _pair_table(dsts, srcs, "multi_copy")
+    if n:
+        call("eeggan_multi_copy", table, n, _stream())
+
+
+def multi_add_(dsts, srcs):
+    """dsts[k] += srcs[k] for two lists of tensors, in one launch."""
+    table, n = _pair_table(dsts, srcs, "multi_add")
+    if n:
+        call("eeggan_multi_axpby", table, n, 1.0, 1.0, _stream())
+
+
 def wgan_gp_d_loss_stacked(scores, g, drift, lam, target):
     """``wgan_gp_d_loss(scores[:B], scores[B:], ...)`` without slicing the scores."""
     return _WganGpLossStacked.apply(scores, g, float(drift), float(lam), float(target))
