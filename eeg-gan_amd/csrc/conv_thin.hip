@@ -5,6 +5,7 @@
 // the wide side, every load and store of a wave a run of full cache lines.  Same epilogues and fused
 // input mask as the matrix-core kernels (bias -> activation -> per-(sample, channel) multiplier).
 #include "common.h"
+#include <cstdlib>
 #include "conv_args.h"
 
 #include <cstdint>
@@ -159,16 +160,28 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs a) {
 
 }  // namespace
 
-// Used when 16-byte accesses are possible and still give the chip two workgroups per CU (about 270
-// samples at T = 1920): measured 0.76-0.79 of the HBM peak there against 0.36-0.38 for the matrix-core
-// kernel, which pads the thin side to a 32-channel chunk.  Below that size a launch is bound by latency
-// (one thread walks the whole wide side) and the matrix-core kernel, which spreads it, is faster
-// (8.6 vs 15 us at 32 samples).
+// Used when 16-byte accesses are possible and the launch has enough workgroups per CU.  Below that a launch is bound
+// by latency (one thread walks the whole wide side) and the matrix-core kernel, which pads the thin side to a
+// 32-channel chunk but spreads the walk, is faster.  Measured per launch at T = 1920, hot caches, samples 32 / 64 /
+// 96 / 128 / 160 / 256: thin OUTPUT side (to_rgb, 64 -> 5) matrix cores 13 / 18 / 27 / 35 / 42 / 65 us, this kernel
+// - / 21 / 21 / 22 / 26 / 27 us: taken from half a workgroup per CU (~70 samples); thin INPUT side (from_rgb, 5 -> 64)
+// matrix cores 13 / 16 / 22 / 33 / 39 / 45 us, this kernel - / 32 / 32 / 33 / 35 / 36 us: from one workgroup per CU
+// (~140 samples).  At 512 samples it runs at 0.76-0.79 of the HBM peak against 0.36-0.38.
+// (EEGGAN_THIN_MIN_WG_PER_CU overrides both thresholds: comparison runs.)
+static long long thin_min_items(bool thin_output) {
+    static const double forced = [] {
+        const char* e = std::getenv("EEGGAN_THIN_MIN_WG_PER_CU");
+        return e ? std::atof(e) : -1.0;
+    }();
+    const double per_cu = forced >= 0.0 ? forced : (thin_output ? 0.5 : 1.0);
+    return (long long)(256.0 * per_cu * num_cus());
+}
+
 int launch_conv_thin(const ConvArgs& a, int K, hipStream_t st) {
     const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool typed = a.x_bf16 || a.y_bf16;  // (the matrix-core kernel has no bfloat16 form for these layers)
     if (K != 1 || (a.Cin > THIN && a.Cout > THIN) || a.act == ACT_LRELU_PN || !a.vec || !al16(a.x) || !al16(a.y) ||
-        !al16(a.mask_y) || !al16(a.act_aux) || (!typed && (long long)a.B * (a.T / 4) < 256ll * 2 * num_cus()))
+        !al16(a.mask_y) || !al16(a.act_aux) || (!typed && (long long)a.B * (a.T / 4) < thin_min_items(a.Cout <= THIN)))
         return -1;
     const long long items = (long long)a.B * (a.T / 4);
     const unsigned grid = (unsigned)((items + 255) / 256);

@@ -250,38 +250,47 @@ class ConditionalBatchNorm(nn.Module):
                             spectral=spectral, bias=False))
             self.mode = "SM" if num_classes == 0 else "CSM"
 
-    @staticmethod
-    def _one_step(t, what):
-        t = t.unsqueeze(2) if t.dim() == 2 else t
-        if t.shape[2] != 1:
-            raise NotImplementedError(f"ConditionalBatchNorm: {what} with a time axis")
-        return t
-
-    def modulation(self, z, y=None):
-        """(gamma, beta), each [B, num_features], from the latent [B, latent(, 1)] and / or the class embedding
-        [B, classes(, 1)]; (None, None) in 'BN' mode."""
-        if self.mode == "BN":
-            return None, None
+    def _conditioning(self, z, y):
+        """The modulation network's input (layers.py:121-130): the class embedding ('CBN'), the latent ('SM') or the
+        latent's channels followed by the embedding's, the latent resampled to the embedding's length ('CSM');
+        [B, channels, steps] with one step for per-sample conditioning."""
+        as3 = lambda t: t.unsqueeze(2) if t.dim() == 2 else t  # noqa: E731
         if self.mode in ("CBN", "CSM"):
             if y is None:
                 raise ValueError(f"ConditionalBatchNorm in '{self.mode}' mode needs the class embedding")
-            y = self._one_step(y, "a class embedding")
+            y = as3(y)
         if self.mode in ("SM", "CSM"):
             if z is None:
                 raise ValueError(f"ConditionalBatchNorm in '{self.mode}' mode needs the latent")
-            z = self._one_step(z, "a latent")
+            z = as3(z)
         if self.mode == "CBN":
-            cond = y
-        elif self.mode == "SM":
-            cond = z
-        else:  # (layers.py:125-127) the latent's channels, then the embedding's
-            nz, ny = z.shape[1], y.shape[1]
-            cond = ops.channel_window(y, ops.channel_window(z, None, 0, 0, nz, channels=nz + ny, length=1), 0, nz, ny)
-        e = self.embed(cond)  # [B, 2 F, 1]
-        n = self.num_features
-        gamma = ops.channel_window(e, None, 0, 0, n, channels=n, length=1).reshape(e.shape[0], n)
-        beta = ops.channel_window(e, None, n, 0, n, channels=n, length=1).reshape(e.shape[0], n)
-        return gamma, beta
+            return y
+        if self.mode == "SM":
+            return z
+        from .utils import resample_signal
+        z = resample_signal(z.contiguous(), z.shape[2], y.shape[2])
+        nz, ny, steps = z.shape[1], y.shape[1], y.shape[2]
+        return ops.channel_window(y, ops.channel_window(z, None, 0, 0, nz, channels=nz + ny, length=steps), 0, nz, ny)
+
+    def modulation(self, z, y=None, length=None):
+        """(gamma, beta) from the latent [B, latent(, steps)] and / or the class embedding [B, classes(, steps)];
+        (None, None) in 'BN' mode.  Per-sample conditioning (one step) gives [B, num_features] each; conditioning
+        with a time axis is resampled to ``length`` steps, the layer's (layers.py:131-133), and gives
+        [B, num_features, length] each."""
+        if self.mode == "BN":
+            return None, None
+        e = self.embed(self._conditioning(z, y))  # [B, 2 F, steps]
+        n, steps = self.num_features, e.shape[2]
+        if steps == 1:
+            gamma = ops.channel_window(e, None, 0, 0, n, channels=n, length=1).reshape(e.shape[0], n)
+            beta = ops.channel_window(e, None, n, 0, n, channels=n, length=1).reshape(e.shape[0], n)
+            return gamma, beta
+        from .utils import resample_signal
+        if length is None:
+            raise ValueError("ConditionalBatchNorm: conditioning with a time axis needs the layer's length")
+        e = resample_signal(e, steps, length)
+        return (ops.channel_window(e, None, 0, 0, n, channels=n, length=length),
+                ops.channel_window(e, None, n, 0, n, channels=n, length=length))
 
     # the critic's norms are differentiated twice (gradient penalty): the Discriminator sets this, and the layer then
     # runs as a chain of multilinear pieces instead of the fused first-order kernel pair
@@ -292,9 +301,18 @@ class ConditionalBatchNorm(nn.Module):
         bn = self.normalizer
         train = self.training or bn.running_mean is None
         momentum = 0.1 if bn.momentum is None else bn.momentum
-        gmod, bmod = self.modulation(z, y)
+        gmod, bmod = self.modulation(z, y, length=c.shape[2])
         if train and bn.track_running_stats:
             bn.num_batches_tracked += 1
+        if gmod is not None and gmod.dim() == 3:
+            # conditioning with a time axis (layers.py:131-134): the norm alone, then out + gamma * out + beta with
+            # full-size gamma / beta, then the layer's activation and multipliers
+            if self.second_order:
+                raise NotImplementedError("a modulated batch norm that is differentiated twice")
+            o = ops.bn_act(c, None, bn.weight, bn.bias, None, None, bn.running_mean, bn.running_var, 1.0, bn.eps,
+                           momentum, train)
+            o = ops.axpby(ops.axpby(o, 1.0, ops._Product.apply(o, gmod), 1.0), 1.0, bmod, 1.0)
+            return o if (drop is None and slope == 1.0) else ops.lrelu_drop(o, drop, slope)
         if self.second_order:
             if self.mode != "BN":
                 raise NotImplementedError("a latent-modulated batch norm that is differentiated twice")

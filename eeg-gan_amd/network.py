@@ -140,7 +140,7 @@ class Generator(nn.Module):
                  rgb_generation_mode="pggan"):
         super().__init__()
         _require(num_classes == 0 or act_norm == "batch", "class conditioning without batch norm layers")
-        _require(not conv_only or not (z_to_bn or split_z), "conv_only with z_to_bn / split_z")
+        _require(not conv_only or not split_z, "conv_only with split_z")
         _require(not z_to_bn or (act_norm == "batch" and not deep), "z_to_bn without batch norm layers, or in deep blocks")
         if rgb_generation_mode not in ("pggan", "residual", "mean"):
             raise ValueError("invalid rgb_generation_mode: {}".format(rgb_generation_mode))

@@ -19,6 +19,10 @@ CASES = {
     "csm": dict(shared=dict(num_classes=3), generator=dict(act_norm="batch", z_to_bn=True)),
     "cbn_raw_classes": dict(shared=dict(num_classes=5, equalized=False),
                             generator=dict(act_norm="batch", shared_embedding_size=0), discriminator=dict(spectral=True)),
+    # class scores with a time axis (layers.py:121-134); the reference's critic takes per-sample classes only
+    "cbn_timed": dict(shared=dict(num_classes=4), generator=dict(act_norm="batch"), critic_without_classes=True),
+    "csm_timed": dict(shared=dict(num_classes=3), generator=dict(act_norm="batch", z_to_bn=True),
+                      critic_without_classes=True),
 }
 
 
@@ -64,7 +68,8 @@ def test_oracle_matches_reference(name):
     fake = O.generator_forward(gp, gs, z, depth, alpha, cfg, O.DropSource("numpy"), y=y)
     x_in = real.clone().requires_grad_(True)
     np.random.seed(seed + 1)
-    score, _ = O.discriminator_forward(dp, ds, x_in, depth, alpha, cfg, O.DropSource("numpy"), y=y)
+    score, _ = O.discriminator_forward(dp, ds, x_in, depth, alpha, cfg, O.DropSource("numpy"),
+                                       y=None if case.get("critic_without_classes") else y)
     (gx,) = torch.autograd.grad(score.sum(), x_in, create_graph=True)
     l_g, l_d = _functionals(fake, r1, score, gx, r2)
     assert rel(fake, c["fake"]) < 1e-9 and rel(score, c["score"]) < 1e-9
@@ -116,7 +121,7 @@ def test_against_reference_fixture(dev, name):
         fake = g(jitter(z), y)[0]["x"]
         x_in = jitter(real).clone().requires_grad_(True)
         np.random.seed(seed + 1)
-        score = d(x_in, y)[0]
+        score = d(x_in, None if case.get("critic_without_classes") else y)[0]
         (gx,) = torch.autograd.grad(score.sum(), x_in, create_graph=True)
         l_g, l_d = _functionals(fake, r1, score, gx, r2)
         grads = {"g": dict(zip([k for k, _ in g.named_parameters()],

@@ -40,7 +40,7 @@ def test_unsupported_options_raise():
     noisy = Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "per_channel_noise": True})
     assert "blocks.6.noises.1" in noisy.state_dict() and float(noisy.block0.noises[0].abs().sum()) == 0.0
     with pytest.raises(NotImplementedError):
-        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True, "split_z": True})
+        Generator(**kw, z_distribution="normal", **{**config.GENERATOR_KWARGS, "conv_only": True, "split_z": True, "act_norm": "batch"})
     with pytest.raises(NotImplementedError):
         Discriminator(**kw, **{**config.DISCRIMINATOR_KWARGS, "act_norm": "layer"})
     with pytest.raises(NotImplementedError):  # (classes enter the generator through its batch norms only)

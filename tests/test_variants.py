@@ -50,6 +50,8 @@ CASES = {
     "per_channel_noise": dict(generator=dict(per_channel_noise=True), noise_weights=True),
     "per_channel_noise_deep": dict(shared=dict(deep=True), generator=dict(per_channel_noise=True, act_norm="batch"),
                                    noise_weights=True),
+    "conv_only_z_to_bn": dict(generator=dict(conv_only=True, act_norm="batch", z_to_bn=True),
+                              discriminator=dict(conv_only=True)),
     "temporal_groups": dict(discriminator=dict(temporal_groups_per_window=2)),
     "temporal_groups_ragged": dict(discriminator=dict(temporal_groups_per_window=5, group_size=2)),
 }

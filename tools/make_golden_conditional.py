@@ -31,6 +31,13 @@ CASES = {
     "csm": dict(shared=dict(num_classes=3), generator=dict(act_norm="batch", z_to_bn=True), depth=1, alpha=1.0),
     "cbn_raw_classes": dict(shared=dict(num_classes=5, equalized=False), generator=dict(act_norm="batch", shared_embedding_size=0),
                             discriminator=dict(spectral=True), depth=2, alpha=1.0),
+    # class scores with a time axis (16 steps): the modulation of every batch norm is resampled to its layer's length
+    # (layers.py:121-134).  The reference's critic takes per-sample classes only (its embedding is an nn.Linear on the
+    # last axis, network.py:518-519, 555-557): it is evaluated without classes here
+    "cbn_timed": dict(shared=dict(num_classes=4), generator=dict(act_norm="batch"), depth=2, alpha=0.6, y_steps=16,
+                      critic_without_classes=True),
+    "csm_timed": dict(shared=dict(num_classes=3), generator=dict(act_norm="batch", z_to_bn=True), depth=1, alpha=1.0,
+                      y_steps=8, critic_without_classes=True),
 }
 
 
@@ -75,6 +82,9 @@ def main():
         torch.manual_seed(seed)
         z32 = torch.randn(batch, cfgmod.LATENT_SIZE)
         y32 = torch.nn.functional.one_hot(torch.randint(classes, (batch,)), classes).float() + 0.1 * torch.randn(batch, classes)
+        if "y_steps" in case:  # class scores per time step: [B, classes, steps]
+            y32 = (y32.unsqueeze(2) + 0.5 * torch.randn(batch, classes, case["y_steps"])).contiguous()
+        d_y = (lambda y: None) if case.get("critic_without_classes") else (lambda y: y)
         r1_32, r2_32 = torch.randn(batch, cfgmod.NUM_CHANNELS, T), torch.randn(batch)
 
         def run_ref(dtype):
@@ -88,7 +98,7 @@ def main():
             fake = g(z, y)[0]["x"]
             x_in = real.clone().requires_grad_(True)
             np.random.seed(seed + 1)
-            score = d(x_in, y)[0]
+            score = d(x_in, d_y(y))[0]
             (gx,) = torch.autograd.grad(score.sum(), x_in, create_graph=True)
             l_g, l_d = functionals(fake, r1, score, gx, r2)
             g_grads = dict(zip([k for k, _ in g.named_parameters()],
@@ -109,7 +119,7 @@ def main():
         ofake = O.generator_forward(gp, gs, z, depth, alpha, cfg, O.DropSource("numpy"), y=y)
         x_in = real.clone().requires_grad_(True)
         np.random.seed(seed + 1)
-        oscore, _ = O.discriminator_forward(dp, ds, x_in, depth, alpha, cfg, O.DropSource("numpy"), y=y)
+        oscore, _ = O.discriminator_forward(dp, ds, x_in, depth, alpha, cfg, O.DropSource("numpy"), y=d_y(y))
         (ogx,) = torch.autograd.grad(oscore.sum(), x_in, create_graph=True)
         ol_g, ol_d = functionals(ofake, r1, oscore, ogx, r2)
         assert M.rel(ofake, fake) < 1e-9 and M.rel(oscore, score) < 1e-9, (name, M.rel(ofake, fake), M.rel(oscore, score))

@@ -73,6 +73,10 @@ CASES = {
     "per_channel_noise": dict(generator=dict(per_channel_noise=True), depth=2, alpha=0.6, noise_weights=True),
     "per_channel_noise_deep": dict(shared=dict(deep=True), generator=dict(per_channel_noise=True, act_norm="batch"),
                                    depth=1, alpha=1.0, noise_weights=True),
+    # a fully convolutional generator whose batch norms are modulated by the latents [B, 256, 32]: conditioning with a
+    # time axis, resampled to every layer's length (layers.py:121-134)
+    "conv_only_z_to_bn": dict(generator=dict(conv_only=True, act_norm="batch", z_to_bn=True),
+                              discriminator=dict(conv_only=True), depth=2, alpha=0.7, z_len=32),
     "temporal_groups": dict(discriminator=dict(temporal_groups_per_window=2), depth=2, alpha=1.0),
     "temporal_groups_ragged": dict(discriminator=dict(temporal_groups_per_window=5, group_size=2), depth=1, alpha=0.5),
 }
