@@ -40,6 +40,24 @@ __global__ __launch_bounds__(256) void resample_kernel(const TI* __restrict__ x,
     }
 }
 
+// The same gather for tables wider than RS_MAXTAPS (the transpose of an upsampling by p has about 2 p + 2 taps per
+// position: conditioning signals of a few steps stretched to a layer's length): the taps are walked in a loop
+// instead of living in registers.  One thread per (output position, row).
+constexpr int RS_WIDE_MAXTAPS = 1024;
+
+template <typename TI = float, typename TO = float>
+__global__ __launch_bounds__(256) void resample_wide_kernel(const TI* __restrict__ x, const int32_t* __restrict__ idx,
+                                                            const float* __restrict__ coef, TO* __restrict__ out,
+                                                            long long rows, int Tin, int Tout, int taps) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const long long row = blockIdx.y;
+    if (m >= Tout || row >= rows) return;
+    const TI* xr = x + row * Tin;
+    float s = 0.f;
+    for (int k = 0; k < taps; ++k) s += coef[(long long)m * taps + k] * ld1(xr + idx[(long long)m * taps + k]);
+    st1(out + row * Tout + m, s);
+}
+
 // Quad form: a thread produces 4 consecutive output positions (one 16-byte store per row).  Their taps
 // fall into a span of at most 4*NV input samples starting at base[q] (a multiple of 4), which the thread
 // loads as NV 16-byte vectors; the host hands the taps over as a dense 4 x (4*NV) coefficient block per
@@ -319,11 +337,17 @@ static int resample_impl(const TI* x, const int32_t* idx, const float* coef, TO*
                          int taps, void* stream) {
     EEGGAN_REQUIRE(x && idx && coef && out, "resample: null pointer");
     EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample: non-positive dimension");
-    EEGGAN_REQUIRE(taps >= 1 && taps <= RS_MAXTAPS, "resample: taps %d outside [1, %d]", taps, RS_MAXTAPS);
+    EEGGAN_REQUIRE(taps >= 1 && taps <= RS_WIDE_MAXTAPS, "resample: taps %d outside [1, %d]", taps, RS_WIDE_MAXTAPS);
+    hipStream_t st = as_stream(stream);
+    if (taps > RS_MAXTAPS) {
+        EEGGAN_REQUIRE(rows <= 65535u * 1024u, "resample: too many rows");
+        hipLaunchKernelGGL((resample_wide_kernel<TI, TO>), dim3((Tout + 255) / 256, (unsigned)rows), dim3(256), 0, st, x, idx,
+                           coef, out, (long long)rows, Tin, Tout, taps);
+        return check_launch("resample");
+    }
     const size_t gy = (rows + RS_ROWS - 1) / RS_ROWS;
     EEGGAN_REQUIRE(gy <= 65535u * 1024u, "resample: too many rows");
     dim3 grid((Tout + 255) / 256, (unsigned)gy);
-    hipStream_t st = as_stream(stream);
 #define RS_CASE(N)                                                                                              \
     case N:                                                                                                     \
         hipLaunchKernelGGL((resample_kernel<N, TI, TO>), grid, dim3(256), 0, st, x, idx, coef, out, (long long)rows, Tin, \

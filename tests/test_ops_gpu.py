@@ -575,6 +575,28 @@ def test_minibatch_stddev_orders(dev, B):
     assert float(err) < 5 * TOL
 
 
+@pytest.mark.parametrize("t_in,t_out", [(16, 256), (8, 128), (256, 16), (4, 512)])
+def test_resample_large_ratios(dev, t_in, t_out):
+    """Ratios far beyond the progression's (a conditioning signal of a few steps stretched to a layer's length,
+    reference layers.py:128, 132): the transposed table of an upsampling by 16 has 40 taps per position, more than
+    the register-resident kernel holds; forward and transpose against torch's interpolate / avg_pool in fp64."""
+    from eeggan_amd.utils import resample_signal
+    g = torch.Generator().manual_seed(t_in + t_out)
+    x = torch.randn(3, 7, t_in, generator=g)
+    x64 = x.double().requires_grad_(True)
+    if t_out > t_in:
+        ref = F.interpolate(x64, scale_factor=t_out // t_in, mode="linear", align_corners=False)
+    else:
+        ref = F.avg_pool1d(x64, t_in // t_out, t_in // t_out)
+    xd = x.to(dev).requires_grad_(True)
+    y = resample_signal(xd, t_in, t_out)
+    assert tuple(y.shape) == tuple(ref.shape) and rel(y, ref) < 5e-6
+    gy = torch.randn(ref.shape, generator=g)
+    (gx_ref,) = torch.autograd.grad(ref, x64, gy.double())
+    (gx,) = torch.autograd.grad(y, xd, gy.to(dev))
+    assert rel(gx, gx_ref) < 5e-6
+
+
 @pytest.mark.parametrize("T,stride,segments", [(32, 16, 1), (32, 6, 1), (48, 32, 2), (40, 8, 2)])
 def test_minibatch_stddev_temporal_windows(dev, T, stride, segments):
     """Statistics per temporal window of ``stride`` steps (reference layers.py:72, 81-89; a last window shorter
