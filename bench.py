@@ -223,10 +223,9 @@ def measured_traffic():
 def conv_ws_family_flops(trainer_factory):
     """Algorithmic flops per training step of all launches that take the weight-stationary kernel (k = 3, at
     most 64 channels on both sides, >= 256 subtiles: the library's own dispatch rule), counted over one eager
-    step with the same models; with the family's kernel time from a rocprofv3 trace this gives the in-step
-    figure next to the stand-alone one."""
+    step with the same models, and the list of those launches (shapes and which optional operands they carry)."""
     from eeggan_amd import ops
-    total = [0.0, 0]
+    total = [0.0, 0, []]
     raw = ops.conv1d_raw
 
     def counted(x, w, *a, **k):
@@ -236,6 +235,9 @@ def conv_ws_family_flops(trainer_factory):
         if K == 3 and Cin <= 64 and 32 < Cout <= 64 and T % 4 == 0 and B * ((T + 31) // 32) >= 256:
             total[0] += 2.0 * B * Cin * Cout * K * T
             total[1] += 1
+            bias, drop = (list(a) + [None, None])[:2] if a else (k.get("bias"), k.get("drop"))
+            total[2].append(("conv", (B, Cin, Cout, T), bool(k.get("transposed")), int(k.get("act", 0)), bias is not None,
+                             drop is not None, k.get("mask_y") is not None, k.get("mask_drop") is not None))
         return raw(x, w, *a, **k)
 
     fused = ops.conv1d_pixelnorm_raw
@@ -245,6 +247,7 @@ def conv_ws_family_flops(trainer_factory):
         if out is not None:
             total[0] += 2.0 * x.shape[0] * x.shape[1] * w.shape[0] * w.shape[2] * x.shape[2]
             total[1] += 1
+            total[2].append(("conv_pn", (x.shape[0], x.shape[1], w.shape[0], x.shape[2])))
         return out
 
     ops.conv1d_raw, ops.conv1d_pixelnorm_raw = counted, counted_fused
@@ -255,6 +258,60 @@ def conv_ws_family_flops(trainer_factory):
     finally:
         ops.conv1d_raw, ops.conv1d_pixelnorm_raw = raw, fused
     return total
+
+
+def family_chain(dev, launches):
+    """The weight-stationary family's launches of one training step (as recorded by ``conv_ws_family_flops``: same
+    shapes, same epilogues and masks, same order) captured as ONE dependent chain in a HIP graph and replayed:
+    milliseconds per replay by HIP events on the replay stream.  Unlike the stand-alone figure this one pays what
+    every launch of the step pays -- the launch boundary inside a graph, a prologue and a partly filled round per
+    layer, all of the step's layer sizes -- but nothing of the other kernels of the step or of the second chain that
+    shares the chip with it; unlike a profiler's per-kernel durations it is measured on the unprofiled launch path."""
+    from eeggan_amd import ops
+    cache, flips = {}, {}
+
+    def flipped(w):  # the flipped view an input gradient reads: kept per weight, as the layers keep theirs
+        if id(w) not in flips:
+            flips[id(w)] = ops.FlipCache(w)
+        return flips[id(w)]
+
+    def tensor(*shape):
+        if shape not in cache:
+            cache[shape] = torch.randn(*shape, device=dev) if len(shape) != 2 else torch.rand(*shape, device=dev) + 0.5
+        return cache[shape]
+
+    def run():
+        for rec in launches:
+            if rec[0] == "conv_pn":
+                B, Cin, Cout, T = rec[1]
+                ops.conv1d_pixelnorm_raw(tensor(B, Cin, T), tensor(Cout, Cin, 3), tensor(Cout), tensor(B, Cout),
+                                         in_scale=0.1, slope=0.2)
+                continue
+            _, (B, Cin, Cout, T), transposed, act, has_bias, has_drop, has_mask, has_mask_drop = rec
+            w = tensor(Cin, Cout, 3) if transposed else tensor(Cout, Cin, 3)
+            ops.conv1d_raw(tensor(B, Cin, T), w, tensor(Cout) if has_bias else None,
+                           tensor(B, Cout) if has_drop else None, in_scale=0.1, transposed=transposed, act=act,
+                           act_param=0.2, act_aux=tensor(B, Cout, T) if act == 3 else None,
+                           mask_y=tensor(B, Cin, T) if has_mask else None,
+                           mask_drop=tensor(B, Cin) if has_mask_drop else None, mask_slope=0.2,
+                           flip=flipped(w) if transposed else None)
+
+    run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def device_info(dev):
@@ -268,13 +325,18 @@ def device_info(dev):
     return info
 
 
-def in_step_figures(flops, launches):
+def in_step_figures(flops, launches, chain_ms=None):
     """The weight-stationary family inside the training step: flops counted live; kernel time per step from the
     committed rocprofv3 kernel-trace summary of this command -- a figure of the session and box that wrote that
     file, not of this run, which is why it carries the file's library id and is left out (``stale``) when the
     summary belongs to another build of the library than the one in use."""
     from eeggan_amd import _lib
     out = {"family": "conv_ws_kernel<*>", "flop_per_step": flops, "launches_per_step": launches}
+    if chain_ms:
+        # measured live: the family's launches of a step replayed as one dependent chain of a HIP graph
+        out["chain"] = {"ms_per_step": round(chain_ms, 3), "achieved": round(flops / (chain_ms * 1e-3) / 1e12, 2),
+                        "frac": round(flops / (chain_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "how": "the step's launches of the family, in order, as one captured chain; HIP events"}
     path = os.path.join(ROOT, PER_KERNEL)
     if not os.path.exists(path):
         return out
@@ -439,7 +501,8 @@ def main():
         # (the committed per-kernel profile belongs to the headline configuration only)
         headline = args.batch == 32 and args.depth == 7 and args.alpha == 1.0 and args.dtype == "f32" and args.storage == "f32"
         if headline:
-            out["roofline"]["in_step"] = in_step_figures(*fam)
+            chain_ms = family_chain(dev, fam[2]) if fam[2] else None
+            out["roofline"]["in_step"] = in_step_figures(fam[0], fam[1], chain_ms)
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP32_MFMA_PEAK_TFLOPS
         step_flop = config.step_flops(args.depth, args.batch)
         out["roofline"]["whole_step"] = {

@@ -64,6 +64,24 @@ def run(B):
             row(f"conv fwd+lrelu+pixelnorm+gdrop {tag}",
                 timeit(lambda: ops.conv1d_pixelnorm_raw(x, w, b, r, in_scale=0.1, slope=0.2), n), flop=fl)
         del x, w, b, r, gy
+    # The weight gradients as the training step submits them: the k = 3 layers of one critic backward pass in ONE
+    # grouped launch (the workgroups dealt out over the layers in proportion to their work) plus the multi-job slab
+    # sums -- the single-layer "wgrad+reduce" rows above are the stand-alone entry point, which the step does not use.
+    if B <= 64:
+        layers = [(64, 64, 1920)] * 2 + [(64, 64, 1280)] * 2 + [(64, 64, 1024)] * 2 + [(64, 64, 768)] * 2 + \
+                 [(64, 64, 512), (64, 128, 512), (128, 128, 256), (128, 256, 256), (256, 256, 128), (256, 256, 128),
+                  (256, 256, 32)]
+        gen = torch.Generator(device=dev).manual_seed(1)
+        jobs = []
+        for cin, cout, T in layers:
+            x = torch.randn(B, cin, T, device=dev, generator=gen)
+            gy = torch.randn(B, cout, T, device=dev, generator=gen)
+            y = torch.randn(B, cout, T, device=dev, generator=gen)
+            r = torch.rand(B, cout, device=dev, generator=gen) + 0.5
+            jobs.append(dict(x=x, gy=gy, K=3, in_scale=0.1, mask_y=y, mask_drop=r, mask_slope=0.2))
+        fl = sum(2.0 * B * cin * cout * 3 * T for cin, cout, T in layers)
+        row(f"grouped wgrad + slab sums, {len(layers)} critic layers", timeit(lambda: ops.conv1d_wgrad_group_raw(jobs), n), flop=fl)
+        del jobs
     # 1x1 convs on five channels: bandwidth-bound
     for cin, cout in ((64, 5), (5, 64)):
         T = 1920
