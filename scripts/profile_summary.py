@@ -6,8 +6,9 @@ Only the last `steps` (default 10) training steps of the trace are counted: a st
 Adam launch (five critic updates and one generator update), so the window runs from the Adam launch that
 closes the step before them to the one that closes the last; warm-up, graph capture and the stand-alone
 kernel timing that follows the timed region stay outside.  The launches of the weight-stationary conv kernel
-AFTER the last optimizer launch are that stand-alone timing (`bench.py`'s roofline figure, one shape launched
-back to back); their mean duration is printed for comparison with the HIP-event figure in the bench line."""
+right AFTER the last optimizer launch (the first 105) are that stand-alone timing (`bench.py`'s roofline figure, one
+shape launched back to back); their mean duration is printed for comparison with the HIP-event figure in the bench
+line.  (The family's chain of a whole step, which `bench.py` replays after them, follows and is not counted.)"""
 import collections
 import csv
 import os
@@ -39,6 +40,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f"{k:74s} n/step={v[1] / steps:7.1f} ms/step={v[0] / steps / 1e6:7.3f} ({100.0 * v[0] / total:4.1f}%) "
           f"avg={v[0] / v[1] / 1e3:7.1f}us")
 tail = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[last + 1:] if "conv_ws_kernel" in r["Kernel_Name"]]
+tail = tail[:105]  # 5 warm-up launches and two timed runs of 50; what follows is the family's chain (all layer sizes)
 if tail:
     timed = tail[len(tail) // 5:]  # the first launches are the warm-up of that loop
     print(f"stand-alone roofline launches after the timed steps: {len(tail)} of conv_ws_kernel, mean of the last "
