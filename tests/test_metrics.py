@@ -264,3 +264,76 @@ def test_swd_direction_chunks(dev):
     torch.manual_seed(5)
     got = parts.sliced_wasserstein(a, b)
     assert abs(got - want) < 1e-6 * abs(want), (got, want)
+
+
+@pytest.mark.gpu
+def test_feature_pipeline_at_the_stated_size(dev):
+    """The evaluation workload at the size the configuration states (100 000 generated [5, 1920] signals: generator
+    inference at the final stage, ``Network.forward(no_loss=True)``, mean and covariance of the four latents, Frechet
+    distances; reference network.py:354-396, cpc_network.py:316-322, plugins.py:503-572), checked through properties
+    that do not depend on the size: the latents of signals picked from all over the 100 000 equal the CPU
+    restatement's (1e-4); the statistics of the 3.2 M x 128 feature matrix equal a float64 evaluation on the device
+    (mean 1e-5, covariance 1e-4 -- single precision sums of millions of rows, in a fixed order); the distance is
+    symmetric, and zero from a set to itself, to 1e-3 of tr(cov_1) + tr(cov_2): the distance is what is left of those
+    traces after the cross term is taken off them (plugins.py:566-572), and the cross term comes out of fifty
+    single-precision Newton-Schulz iterations, whose root is good to 1e-3 (the bar of the fixture test above; measured
+    here: 3e-4 of the traces from a set to itself, 5e-5 between the two orders)."""
+    from eeggan_amd import config, cpc, layers
+    from eeggan_amd.dataset import synthetic_eeg
+    from eeggan_amd.plugins import FidCalculator
+    from oracle import metrics_cpu as M
+    N, B = 100000, 2048
+    layers.set_drop_mode("device")
+    try:
+        g, _ = config.build_models(config.RANDOM_SEED)
+        g = g.to(dev).eval()
+        g.depth, g.alpha = 7, 1.0
+        T = config.seq_len(7)
+        torch.manual_seed(21)
+        net = cpc.Network(config.NUM_CHANNELS).to(dev).eval()
+        gen = torch.Generator(device=dev).manual_seed(1373)
+        fake = torch.empty(N, config.NUM_CHANNELS, T, device=dev)
+        with torch.no_grad():
+            for i in range(0, N, B):
+                n = min(B, N - i)
+                fake[i:i + n] = g({"z": torch.randn(n, config.LATENT_SIZE, device=dev, generator=gen)})[0]["x"]
+    finally:
+        layers.set_drop_mode("numpy")
+    assert bool(torch.isfinite(fake).all()) and float(fake.abs().max()) <= 1.0
+    pool = torch.from_numpy(synthetic_eeg(2048, config.NUM_CHANNELS, T, np.random.default_rng(1373))).to(dev)
+    real = pool[torch.randint(0, 2048, (N,), device=dev, generator=gen)]
+
+    def features(x):
+        z = torch.empty(N, 128, T // 60, device=dev)
+        c, zp = torch.empty_like(z), torch.empty(N, 128, device=dev)
+        cp = torch.empty_like(zp)
+        with torch.no_grad():
+            for i in range(0, N, B):
+                lat = net(x[i:i + B], no_loss=True).latents
+                z[i:i + B], c[i:i + B], zp[i:i + B], cp[i:i + B] = lat.z, lat.c, lat.z_p, lat.c_p
+        return {"z": z, "c": c, "zp": zp, "cp": cp}
+
+    f_fake, f_real = features(fake), features(real)
+    # latents of signals from all over the set (the last, partly filled batch included) against the CPU restatement
+    pick = torch.tensor([0, 1, 2047, 2048, 50000, 77777, N - 2, N - 1], device=dev)
+    sd = {k: (v.detach().double().cpu() if v.is_floating_point() else v.cpu()) for k, v in net.state_dict().items()}
+    want = M.cpc_forward(sd, fake[pick].double().cpu())
+    for name, w in zip(("z", "c", "zp", "cp"), want):
+        assert rel(f_fake[name][pick], w) < 1e-4, (name, rel(f_fake[name][pick], w))
+    # (the [N, 128, 32] latents as 128-column matrices, reshaped the way the plugin's feature extraction does)
+    flat = lambda f: {k: v.reshape(-1, 128) for k, v in f.items()}  # noqa: E731
+    s_fake = {k: FidCalculator.mean_and_cov(v.contiguous()) for k, v in flat(f_fake).items()}
+    s_real = {k: FidCalculator.mean_and_cov(v.contiguous()) for k, v in flat(f_real).items()}
+    for k, v in flat(f_fake).items():
+        v64 = v.double()
+        mu = v64.mean(0)
+        cov = (v64 - mu).T @ (v64 - mu) / (v64.shape[0] - 1)
+        assert v.shape[0] == (N * (T // 60) if k in ("z", "c") else N)
+        assert rel(s_fake[k][0], mu) < 1e-5 and rel(s_fake[k][1], cov) < 1e-4, (k, rel(s_fake[k][1], cov))
+    for k in s_fake:
+        ab = float(FidCalculator.calc_fid(*s_fake[k], *s_real[k]))
+        ba = float(FidCalculator.calc_fid(*s_real[k], *s_fake[k]))
+        aa = float(FidCalculator.calc_fid(*s_fake[k], *s_fake[k]))
+        scale = float(torch.trace(s_fake[k][1]) + torch.trace(s_real[k][1]))
+        print(f"100 000 signals, latent {k}: distance {ab:.5f}, reversed {ba:.5f}, to itself {aa:.2e}; traces {scale:.3f}")
+        assert ab > 0 and abs(ab - ba) < 1e-3 * scale and abs(aa) < 1e-3 * scale, (k, ab, ba, aa, scale)
