@@ -26,4 +26,4 @@ int check_launch(const char* what) {
 }  // namespace eeggan
 
 extern "C" const char* eeggan_last_error(void) { return eeggan::g_err; }
-extern "C" int eeggan_abi_version(void) { return 3; }
+extern "C" int eeggan_abi_version(void) { return 4; }

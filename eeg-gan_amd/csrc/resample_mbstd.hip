@@ -64,30 +64,35 @@ __global__ __launch_bounds__(256) void resample_wide_kernel(const TI* __restrict
 // quad (zeros where there is no tap), so no address depends on a table value except through base[q].
 // Summation runs over the span in ascending input position: the order of resample_kernel's sorted taps,
 // with exact zero terms in between (the two agree up to the fusing of multiply-adds, ~1 ulp).
+// The coefficient table is lane-interleaved (groups of 64 quads, [e][v][quad % 64][4] inside a group): the 64 lanes
+// of a wave read 1 KB in one piece per load instruction.  With one block per lane in a row every instruction touched
+// 64 lines, the 60-90 KB table fell out of the vector cache between a wave's 8..12 coefficient loads, and a thread had
+// to keep its block for 32 rows to hide that (0.56-0.60 of the HBM peak at 512 samples whatever the rest of the kernel
+// did; a table of three repeating blocks showed 0.72).  Now a thread takes 8 rows, all loads of which are issued
+// before the first is used.  NTS: streaming stores (see st4s); the loads stay cached, neighbouring lanes share
+// their vectors.
 constexpr int RQ_ROWS = 8;
+constexpr int RQ_LANES = 64;  // quads per interleaved group of the coefficient table
 
-template <int NV, typename TI = float, typename TO = float>
+template <int NV, typename TI = float, typename TO = float, bool NTS = false>
 __global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict__ x, const int32_t* __restrict__ base,
                                                             const float* __restrict__ coef, TO* __restrict__ out,
-                                                            long long rows, int Tin, int Tout, int chunks) {
+                                                            long long rows, int Tin, int Tout) {
     // threads are dealt out over (row group, quad) without regard to workgroup borders: Tout/4 is rarely a
     // multiple of 256 (320 at Tout = 1280), and a grid with one axis per row would idle the remainder
     const int NQ = Tout / 4;
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long rg = id / NQ;
     const int q = (int)(id - rg * NQ);
-    // a thread takes `chunks` x RQ_ROWS consecutive rows: its coefficient block (as many bytes as 8 rows of
-    // data) is loaded once for all of them
-    long long r0 = rg * RQ_ROWS * chunks;
+    const long long r0 = rg * RQ_ROWS;
     if (r0 >= rows) return;
     const int b0 = base[q];
     f32x4 cf[4][NV];  // cf[e][v][i]: weight of input b0 + 4v + i in output 4q + e
+    const float* cq = coef + ((long long)(q / RQ_LANES) * (4 * NV) * RQ_LANES + q % RQ_LANES) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-            cf[e][v] = *reinterpret_cast<const f32x4*>(coef + ((long long)q * 4 + e) * (4 * NV) + 4 * v);
-    for (int ch = 0; ch < chunks && r0 < rows; ++ch, r0 += RQ_ROWS) {
+        for (int v = 0; v < NV; ++v) cf[e][v] = *reinterpret_cast<const f32x4*>(cq + (e * NV + v) * RQ_LANES * 4);
     f32x4 xv[RQ_ROWS][NV];
 #pragma unroll
     for (int r = 0; r < RQ_ROWS; ++r) {
@@ -107,8 +112,7 @@ __global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict
                 for (int i = 0; i < 4; ++i) s += cf[e][v][i] * xv[r][v][i];
             o[e] = s;
         }
-        if (r0 + r < rows) st4(out + (r0 + r) * Tout + 4 * q, o);
-    }
+        if (r0 + r < rows) st4s<NTS>(out + (r0 + r) * Tout + 4 * q, o);
     }
 }
 
@@ -388,18 +392,26 @@ static int resample_quads_impl(const TI* x, const int32_t* base, const float* co
     EEGGAN_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                      reinterpret_cast<uintptr_t>(coef)) & 15) == 0,
                    "resample_quads: x, out and coef must be 16-byte aligned");
-    const int chunks = rows >= 16384 ? 4 : 1;  // (large batches: more rows per coefficient block)
-    const size_t per = (size_t)RQ_ROWS * chunks;
-    const size_t threads = (rows + per - 1) / per * (size_t)(Tout / 4);
+    const size_t threads = (rows + RQ_ROWS - 1) / RQ_ROWS * (size_t)(Tout / 4);
     EEGGAN_REQUIRE(threads < ((size_t)1 << 39), "resample_quads: too many rows");
     dim3 grid((unsigned)((threads + 255) / 256));
     hipStream_t st = as_stream(stream);
+    const bool nts = streams_past_caches(rows * ((size_t)Tin * sizeof(TI) + (size_t)Tout * sizeof(TO)));
+#define RQ(NV_, NTS_) \
+    hipLaunchKernelGGL((resample_quad_kernel<NV_, TI, TO, NTS_>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout)
+#define RQN(NV_)                 \
+    do {                         \
+        if (nts) RQ(NV_, true);  \
+        else RQ(NV_, false);     \
+    } while (0)
     switch (nv) {
-        case 1: hipLaunchKernelGGL((resample_quad_kernel<1, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        case 2: hipLaunchKernelGGL((resample_quad_kernel<2, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        case 3: hipLaunchKernelGGL((resample_quad_kernel<3, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
-        default: hipLaunchKernelGGL((resample_quad_kernel<4, TI, TO>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, chunks); break;
+        case 1: RQN(1); break;
+        case 2: RQN(2); break;
+        case 3: RQN(3); break;
+        default: RQN(4); break;
     }
+#undef RQN
+#undef RQ
     return check_launch("resample_quads");
 }
 

@@ -91,6 +91,23 @@ def _pack_quads(rows, t_in: int):
     return base, coef, nv
 
 
+QUAD_LANES = 64
+
+
+def interleave_quads(coef: np.ndarray) -> np.ndarray:
+    """The dense blocks [quads, 4, 4 nv] in the order ``eeggan_resample_quads`` reads them: groups of 64
+    consecutive quads, and inside a group [output e][vector v][quad % 64][4 floats], so that the 64 lanes of a
+    wavefront (consecutive quads) fetch one 16-byte vector each from 1 KB in one piece.  The last group is padded
+    with zeros.  (Block by block -- a lane reading its own 64..256 bytes -- every load instruction touched 64
+    cache lines and the table, 60-90 KB, was fetched again and again: that, not the signal, bounded the kernel.)"""
+    nq, four, width = coef.shape
+    nv = width // 4
+    groups = (nq + QUAD_LANES - 1) // QUAD_LANES
+    padded = np.zeros((groups * QUAD_LANES, 4, nv, 4), dtype=np.float32)
+    padded[:nq] = coef.reshape(nq, 4, nv, 4)
+    return np.ascontiguousarray(padded.reshape(groups, QUAD_LANES, 4, nv, 4).transpose(0, 2, 3, 1, 4)).reshape(-1)
+
+
 def build_tables(t_in: int, p: int, q: int):
     """(forward, transpose) tables as numpy arrays: each is (idx[int32], coef[float32], Tin, Tout, taps,
     quads) with quads = (base[int32], coef[float32], nv) or None."""
@@ -110,7 +127,8 @@ _cache: Dict[Tuple, Tuple] = {}
 
 
 def device_tables(t_in: int, p: int, q: int, device: torch.device):
-    """Device-resident tables, built and uploaded once per (length, ratio, device)."""
+    """Device-resident tables, built and uploaded once per (length, ratio, device); the quad coefficients in the
+    kernel's lane-interleaved order (``interleave_quads``)."""
     fr = Fraction(p, q)
     key = (t_in, fr.numerator, fr.denominator, str(device))
     hit = _cache.get(key)
@@ -118,7 +136,7 @@ def device_tables(t_in: int, p: int, q: int, device: torch.device):
         f, b = build_tables(t_in, fr.numerator, fr.denominator)
         dv = lambda a: torch.from_numpy(a).to(device)
         up = lambda t: (dv(t[0]), dv(t[1]), t[2], t[3], t[4],
-                        None if t[5] is None else (dv(t[5][0]), dv(t[5][1]), t[5][2]))
+                        None if t[5] is None else (dv(t[5][0]), dv(interleave_quads(t[5][1])), t[5][2]))
         hit = (up(f), up(b))
         _cache[key] = hit
     return hit

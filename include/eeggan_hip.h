@@ -230,11 +230,14 @@ int eeggan_resample(const float* x, const int32_t* idx, const float* coef, float
                     size_t rows, int Tin, int Tout, int taps, void* stream);
 /* The same operator in quad form, for tables whose taps are local (every resampler of this path): a thread
  * produces 4 consecutive outputs from the 4*nv input samples starting at base[q] (a multiple of 4, with
- * base[q] + 4*nv <= Tin):  out[r, 4q+e] = sum_{j<4nv} coef[(4q+e)*4nv + j] * x[r, base[q] + j]  -- 16-byte
+ * base[q] + 4*nv <= Tin):  out[r, 4q+e] = sum_{j<4nv} C(q, e, j) * x[r, base[q] + j]  -- 16-byte
  * loads and stores only, no address that depends on a table value but base.  Tin, Tout multiples of 4,
- * nv in [1,4]; x, out, coef 16-byte aligned.  With the dense coefficients = the sparse ones laid out by
- * input position it is the same sum in the same order as eeggan_resample (equal up to how the compiler
- * fuses the multiply-adds: the last bit or two). */
+ * nv in [1,4]; x, out, coef 16-byte aligned.  coef is lane-interleaved: quads in groups of 64 (the last group
+ * padded: ceil(Tout/4 / 64) * 64 * 16 * nv floats in all), and
+ *   C(q, e, 4v + i) = coef[((((q / 64) * 4 + e) * nv + v) * 64 + q % 64) * 4 + i],
+ * so that 64 consecutive quads (the lanes of a wavefront) read each of their vectors from 1 KB in one piece.
+ * With the dense coefficients = the sparse ones laid out by input position it is the same sum in the same order
+ * as eeggan_resample (equal up to how the compiler fuses the multiply-adds: the last bit or two). */
 int eeggan_resample_quads(const float* x, const int32_t* base, const float* coef, float* out,
                           size_t rows, int Tin, int Tout, int nv, void* stream);
 

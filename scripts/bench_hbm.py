@@ -1,21 +1,83 @@
-"""Timing of the bandwidth-bound kernels (pixel norm, resampler) at two batch sizes."""
-import sys, os
+"""Timing of the bandwidth-bound kernels (pixel norm, LeakyReLU backward, blend, resampler) at [B, 64, 1920].
+
+Every launch of a timed loop takes the next of NBUF input sets, so that no launch finds its input in a cache because
+the launch before it read the same bytes (NBUF = 1 is the loop over one tensor of `kernel_roofline.py`).
+
+usage: python scripts/bench_hbm.py [B ...] [--nbuf N]
+"""
+import itertools
+import os
+import sys
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from eeggan_amd import ops, utils
-from kernel_roofline import timeit, row
+from eeggan_amd import ops, utils  # noqa: E402
+from kernel_roofline import timeit, row  # noqa: E402
+
 dev = torch.device("cuda", 0)
-for B in (32, 512):
-    n = 30 if B <= 64 else 8
+
+
+def rotating(fn, sets):
+    """fn(*sets[i]) with i advancing on every call."""
+    turn = itertools.cycle(range(len(sets)))
+    return lambda: fn(*sets[next(turn)])
+
+
+def run(B, nbuf):
+    n = 32 if B <= 64 else 24
     C, T = 64, 1920
-    h = torch.randn(B, C, T, device=dev); g = torch.randn(B, C, T, device=dev); r = torch.rand(B, C, device=dev) + 0.5
-    y, d = ops.pixelnorm_drop_fwd_raw(h, r)
-    row(f"B={B} pixelnorm fwd", timeit(lambda: ops.pixelnorm_drop_fwd_raw(h, r), n), nbytes=2.0 * 4 * B * C * T)
-    row(f"B={B} pixelnorm bwd", timeit(lambda: ops.pixelnorm_drop_bwd_raw(g, y, r, d, 0.2), n), nbytes=3.0 * 4 * B * C * T)
+    r = torch.rand(B, C, device=dev) + 0.5
+    hs = [torch.randn(B, C, T, device=dev) for _ in range(nbuf)]
+    gs = [torch.randn(B, C, T, device=dev) for _ in range(nbuf)]
+    tag = f"B={B} x{nbuf}"
+    y, d = ops.pixelnorm_drop_fwd_raw(hs[0], r)
+    outs = [torch.empty_like(h) for h in hs]
+    row(f"{tag} copy (ATen), calibration", timeit(rotating(lambda h, o: o.copy_(h), list(zip(hs, outs))), n),
+        nbytes=2.0 * 4 * B * C * T)
+    from eeggan_amd._lib import call
+    ds = [torch.empty(B, T, device=dev) for _ in hs]
+    st = torch.cuda.current_stream
+    row(f"{tag} pixelnorm fwd, outputs in turn too",
+        timeit(rotating(lambda h, o, dd: call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), r.data_ptr(), o.data_ptr(), dd.data_ptr(),
+                                              B, C, T, 1e-8, st().cuda_stream), list(zip(hs, outs, ds))), n),
+        nbytes=2.0 * 4 * B * C * T)
+    fn = rotating(lambda h, o, dd: call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), r.data_ptr(), o.data_ptr(), dd.data_ptr(),
+                                        B, C, T, 1e-8, st().cuda_stream), list(zip(hs, outs, ds)))
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    row(f"{tag} pixelnorm fwd, eager launches", e0.elapsed_time(e1) * 1e-3 / n, nbytes=2.0 * 4 * B * C * T)
+    del outs, ds
+    row(f"{tag} pixelnorm fwd", timeit(rotating(lambda h: ops.pixelnorm_drop_fwd_raw(h, r), [(h,) for h in hs]), n),
+        nbytes=2.0 * 4 * B * C * T)
+    row(f"{tag} pixelnorm bwd", timeit(rotating(lambda g, h: ops.pixelnorm_drop_bwd_raw(g, h, r, d, 0.2), list(zip(gs, hs))), n),
+        nbytes=3.0 * 4 * B * C * T)
+    row(f"{tag} lrelu+gdrop bwd", timeit(rotating(lambda g, h: ops.lrelu_drop_bwd_raw(g, h, r, 0.2), list(zip(gs, hs))), n),
+        nbytes=3.0 * 4 * B * C * T)
+    row(f"{tag} axpby (blend)", timeit(rotating(lambda g, h: ops.axpby_raw(h, 0.3, g, 0.7), list(zip(gs, hs))), n),
+        nbytes=3.0 * 4 * B * C * T)
+    del gs
     with torch.no_grad():
-        hc = h[:, :, :1280].contiguous()
-        row(f"B={B} resample 1280->1920", timeit(lambda: utils.resample_signal(hc, 1280, 1920), n), nbytes=4.0 * B * C * 3200)
-        row(f"B={B} resample 1920->1280", timeit(lambda: utils.resample_signal(h, 1920, 1280), n), nbytes=4.0 * B * C * 3200)
-        h2 = h[:, :, :1024].contiguous()
-        row(f"B={B} resample 1024->1280", timeit(lambda: utils.resample_signal(h2, 1024, 1280), n), nbytes=4.0 * B * C * 2304)
-        row(f"B={B} resample 1280->1024", timeit(lambda: utils.resample_signal(hc, 1280, 1024), n), nbytes=4.0 * B * C * 2304)
+        for tin, tout in ((1280, 1920), (1920, 1280), (1024, 1280), (1280, 1024)):
+            xs = [(h[:, :, :tin].contiguous(),) for h in hs]
+            row(f"{tag} resample {tin}->{tout}", timeit(rotating(lambda x: utils.resample_signal(x, tin, tout), xs), n),
+                nbytes=4.0 * B * C * (tin + tout))
+            del xs
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    nbuf = 4
+    if "--nbuf" in args:
+        i = args.index("--nbuf")
+        nbuf = int(args[i + 1])
+        del args[i:i + 2]
+    for B in ([int(a) for a in args] or [32, 512]):
+        run(B, nbuf)

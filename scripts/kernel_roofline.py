@@ -46,7 +46,7 @@ def row(name, t, flop=None, nbytes=None):
 
 
 def run(B):
-    n = 30 if B <= 64 else 8
+    n = 30 if B <= 64 else 24  # (a graph launch costs ~20 us once per replay: 24 launches keep that under 1 % at 100 us each)
     print(f"--- per-GPU batch {B} ---", flush=True)
     convs = [(64, 64, 1920, 3), (64, 64, 1024, 3), (128, 128, 256, 3), (256, 256, 128, 3)]
     for cin, cout, T, K in convs:

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_error_channel():
     from eeggan_amd import _lib
     lib = _lib.load()
-    assert lib.eeggan_abi_version() == 3
+    assert lib.eeggan_abi_version() == 4
     assert isinstance(lib.eeggan_last_error(), bytes)
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.eeggan_conv1d(None, None, None, None, None, 1, 1, 1, 1, 5, 1.0, 0, 0.0, None, None, None, 0.0, None)

@@ -138,6 +138,17 @@ def test_resample_tables_match_interpolate_then_pool():
                 for qq in range(s_out // 4):
                     qfull[4 * qq:4 * qq + 4, base[qq]:base[qq] + 4 * nv] = dense[qq]
                 assert np.array_equal(full, qfull)
+                # the device layout: groups of 64 quads, [e][v][quad % 64][4] inside a group, zero padding at the end
+                from eeggan_amd.resample_tables import interleave_quads
+                flat = interleave_quads(dense)
+                nq = s_out // 4
+                assert flat.shape == ((nq + 63) // 64 * 64 * 16 * nv,)
+                for qq in {0, nq // 2, nq - 1}:
+                    for e in range(4):
+                        for v in range(nv):
+                            at = ((((qq // 64) * 4 + e) * nv + v) * 64 + qq % 64) * 4
+                            assert np.array_equal(flat[at:at + 4], dense[qq, e, 4 * v:4 * v + 4])
+                assert np.array_equal(np.sort(flat[flat != 0]), np.sort(dense[dense != 0]))  # nothing else is non-zero
             assert quads is not None or t_in < 8  # every forward resampler of the schedule has a quad form
             # the transposed table is the adjoint: <A x, g> == <x, A^T g>
             g = torch.randn_like(y)
