@@ -55,9 +55,29 @@ __global__ __launch_bounds__(256) void lrelu_drop_bwd_kernel(const ET* __restric
 // chip: fewer units per workgroup and more channel groups mean more workgroups and a shorter
 // sequential channel loop per thread.
 // CPT > 0: the channel count is CG * CPT and a thread keeps its CPT values in registers between the
-// reduction and the scaling (one read of the input instead of two; all its loads are issued up front).
+// reduction and the scaling (one read of the input instead of two; all its loads are issued up front, and no
+// load stands between its stores: in the CPT = 0 loops every channel costs a round trip to memory, 9-13 us for a
+// 4 MB tensor of the 128- and 256-channel stages).
 // NT (register-resident forms only: the others read their input twice, the second time from the caches): the
 // streaming form, see ld4s.
+// a unit of W time steps as a vector (components past W unused)
+template <int W, bool NT, typename ET>
+__device__ __forceinline__ f32x4 ldw(const ET* p) {
+    if constexpr (W == 4) {
+        return ld4s<NT>(p);
+    } else {
+        return f32x4{ld1(p), 0.f, 0.f, 0.f};
+    }
+}
+template <int W, bool NT, typename ET>
+__device__ __forceinline__ void stw(ET* p, f32x4 v) {
+    if constexpr (W == 4) {
+        st4s<NT>(p, v);
+    } else {
+        st1(p, v[0]);
+    }
+}
+
 template <int W, int CG, int CPT, typename ET = float, bool NT = false>
 __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const ET* __restrict__ h, const float* __restrict__ drop,
                                                             ET* __restrict__ y, float* __restrict__ d, int B, int C,
@@ -78,7 +98,6 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const ET* __restrict
     // store wait for the one before it (loads and stores retire through one counter)
     float rr[CPT > 0 ? CPT : 1];
     if (CPT > 0) {
-        static_assert(CPT == 0 || W == 4, "register-resident form is for the float4 path");
 #pragma unroll
         for (int i = 0; i < CPT; ++i) rr[i] = 1.f;
         if (ok) {
@@ -88,7 +107,7 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const ET* __restrict
             }
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
-                keep[i] = ld4s<NT>(h + ((long long)b * C + cg + i * CG) * T + t);
+                keep[i] = ldw<W, NT>(h + ((long long)b * C + cg + i * CG) * T + t);
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
 #pragma unroll
@@ -131,10 +150,10 @@ __global__ __launch_bounds__(256) void pixelnorm_fwd_kernel(const ET* __restrict
         for (int i = 0; i < CPT; ++i) {
             const int c = cg + i * CG;
             const float r = rr[i];
-            f32x4 o;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < W; ++k) o[k] = keep[i][k] * dv[k] * r;
-            st4s<NT>(y + ((long long)b * C + c) * T + t, o);
+            stw<W, NT>(y + ((long long)b * C + c) * T + t, o);
         }
         return;
     }
@@ -171,7 +190,6 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const ET* __restrict
     f32x4 ka[CPT > 0 ? CPT : 1], kv[CPT > 0 ? CPT : 1];
     float rr[CPT > 0 ? CPT : 1];  // (fetched with the tile, see the forward kernel)
     if (CPT > 0) {
-        static_assert(CPT == 0 || W == 4, "register-resident form is for the float4 path");
 #pragma unroll
         for (int i = 0; i < CPT; ++i) rr[i] = 1.f;
         if (ok) {
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const ET* __restrict
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
                 const long long off = ((long long)b * C + cg + i * CG) * T + t;
-                ka[i] = ld4s<NT>(gy + off);
-                kv[i] = ld4s<NT>(y + off);
+                ka[i] = ldw<W, NT>(gy + off);
+                kv[i] = ldw<W, NT>(y + off);
             }
 #pragma unroll
             for (int i = 0; i < CPT; ++i)
@@ -228,11 +246,11 @@ __global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const ET* __restrict
             const int c = cg + i * CG;
             const float r = rr[i];
             const float ir = 1.f / r;
-            f32x4 o;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < W; ++k)
                 o[k] = dv[k] * (ka[i][k] * r - kv[i][k] * ir * S[k]) * (kv[i][k] > 0.f ? 1.f : slope);
-            st4s<NT>(gc + ((long long)b * C + c) * T + t, o);
+            stw<W, NT>(gc + ((long long)b * C + c) * T + t, o);
         }
         return;
     }
@@ -483,7 +501,7 @@ static int pixelnorm_drop_fwd_impl(const ET* h, const float* drop, ET* y, float*
         PN_FWD(4, 8, 8);
         return check_launch("pixelnorm_drop_fwd");
     }
-    const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;  // channels per thread, register-resident when small
+    const int cpt = C % c.cg == 0 ? C / c.cg : 0;  // channels per thread, register-resident when small
     if (c.w == 4 && c.cg == 4) {
         if (cpt == 16) PN_FWD(4, 4, 16);
         else if (cpt == 32) PN_FWD(4, 4, 32);
@@ -493,8 +511,11 @@ static int pixelnorm_drop_fwd_impl(const ET* h, const float* drop, ET* y, float*
         else if (cpt == 8) PN_FWD(4, 16, 8);
         else if (cpt == 16) PN_FWD(4, 16, 16);
         else PN_FWD(4, 16, 0);
-    } else {
-        if constexpr (sizeof(ET) == 4) PN_FWD(1, 16, 0);
+    } else if constexpr (sizeof(ET) == 4) {
+        if (cpt == 4) PN_FWD(1, 16, 4);
+        else if (cpt == 8) PN_FWD(1, 16, 8);
+        else if (cpt == 16) PN_FWD(1, 16, 16);
+        else PN_FWD(1, 16, 0);
     }
 #undef PN_FWD
 #undef PN_FWD_
@@ -541,7 +562,7 @@ static int pixelnorm_drop_bwd_impl(const ET* gy, const ET* y, const float* drop,
         PN_BWD(4, 8, 8);
         return check_launch("pixelnorm_drop_bwd");
     }
-    const int cpt = (c.w == 4 && C % c.cg == 0) ? C / c.cg : 0;
+    const int cpt = C % c.cg == 0 ? C / c.cg : 0;
     if (c.w == 4 && c.cg == 4) {
         if (cpt == 16) PN_BWD(4, 4, 16);
         else PN_BWD(4, 4, 0);
@@ -550,8 +571,11 @@ static int pixelnorm_drop_bwd_impl(const ET* gy, const ET* y, const float* drop,
         else if (cpt == 8) PN_BWD(4, 16, 8);
         else if (cpt == 16) PN_BWD(4, 16, 16);
         else PN_BWD(4, 16, 0);
-    } else {
-        if constexpr (sizeof(ET) == 4) PN_BWD(1, 16, 0);
+    } else if constexpr (sizeof(ET) == 4) {
+        if (cpt == 4) PN_BWD(1, 16, 4);
+        else if (cpt == 8) PN_BWD(1, 16, 8);
+        else if (cpt == 16) PN_BWD(1, 16, 16);
+        else PN_BWD(1, 16, 0);
     }
 #undef PN_BWD
 #undef PN_BWD_

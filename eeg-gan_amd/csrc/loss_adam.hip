@@ -11,7 +11,31 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
     __shared__ float red[4];
     const float* row = g + (size_t)blockIdx.x * per;
     float s = 0.f;
-    for (size_t i = threadIdx.x; i < per; i += 256) s += row[i] * row[i];
+    if (per % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        // 16-byte loads, eight in flight per thread: one workgroup walks a whole row (9 600 values for a five-channel
+        // signal of 1 920 steps), and with one value per load the walk was 37 dependent round trips
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+        const size_t n4 = per / 4;
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        size_t i = threadIdx.x;
+        for (; i + 7 * 256 < n4; i += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = r4[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] += v[u][e] * v[u][e];
+        }
+        for (; i < n4; i += 256) {
+            const f32x4 v = r4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] += v[e] * v[e];
+        }
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    } else {
+        for (size_t i = threadIdx.x; i < per; i += 256) s += row[i] * row[i];
+    }
     const float tot = block_sum_256(s, red);
     if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(tot);
 }

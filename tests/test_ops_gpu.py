@@ -458,7 +458,8 @@ def test_head_tail(dev, B):
 
 
 @pytest.mark.parametrize("B,C,T", [(4, 64, 1920), (3, 256, 32), (2, 9, 20), (8, 256, 1), (2, 128, 250), (1280, 256, 32), (640, 128, 128),
-                                   (300, 192, 64)])
+                                   (300, 192, 64), (32, 128, 256), (32, 256, 128), (64, 64, 1920),
+                                   (400, 64, 1920)])  # (the last: tensors beyond the caches, the streaming forms)
 def test_pixelnorm_and_masks(dev, B, C, T):
     ops = _ops()
     O = _oracle()
