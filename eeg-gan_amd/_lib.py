@@ -122,6 +122,7 @@ SIGNATURES = {
     "eeggan_conv1d_pixelnorm_t": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _fl, _fl, _fl, _i, _st]),
     "eeggan_resample_t": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
     "eeggan_resample_quads_t": (_i, [_f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "eeggan_resample_quads_affine_t": (_i, [_f, _i, _i, _i, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
     "eeggan_lrelu_drop_bwd_t": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
     "eeggan_pixelnorm_drop_fwd_t": (_i, [_f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),
     "eeggan_pixelnorm_drop_bwd_t": (_i, [_f, _f, _f, _f, _f, _i, _i, _i, _fl, _i, _st]),

@@ -77,7 +77,7 @@ constexpr int RQ_LANES = 64;  // quads per interleaved group of the coefficient 
 template <int NV, typename TI = float, typename TO = float, bool NTS = false>
 __global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict__ x, const int32_t* __restrict__ base,
                                                             const float* __restrict__ coef, TO* __restrict__ out,
-                                                            long long rows, int Tin, int Tout) {
+                                                            long long rows, int Tin, int Tout, int fa, int fc, int fd) {
     // threads are dealt out over (row group, quad) without regard to workgroup borders: Tout/4 is rarely a
     // multiple of 256 (320 at Tout = 1280), and a grid with one axis per row would idle the remainder
     const int NQ = Tout / 4;
@@ -86,7 +86,16 @@ __global__ __launch_bounds__(256) void resample_quad_kernel(const TI* __restrict
     const int q = (int)(id - rg * NQ);
     const long long r0 = rg * RQ_ROWS;
     if (r0 >= rows) return;
-    const int b0 = base[q];
+    // base == nullptr: the quad's start in closed form (an affine function of q, clamped to the row), so that the
+    // loads below wait for no look-up
+    int b0;
+    if (base) {
+        b0 = base[q];
+    } else {
+        const int n = fa * q + fc;
+        b0 = (int)((unsigned)(n > 0 ? n : 0) / (unsigned)fd) & ~3;
+        b0 = b0 < Tin - 4 * NV ? b0 : Tin - 4 * NV;
+    }
     f32x4 cf[4][NV];  // cf[e][v][i]: weight of input b0 + 4v + i in output 4q + e
     const float* cq = coef + ((long long)(q / RQ_LANES) * (4 * NV) * RQ_LANES + q % RQ_LANES) * 4;
 #pragma unroll
@@ -380,10 +389,13 @@ extern "C" int eeggan_resample_quads(const float* x, const int32_t* base, const 
     return eeggan_resample_quads_t(x, base, coef, out, rows, Tin, Tout, nv, 0, 0, stream);
 }
 
+// base == nullptr: the closed form min(max(fa q + fc, 0) / fd / 4 * 4, Tin - 4 nv)
 template <typename TI, typename TO>
 static int resample_quads_impl(const TI* x, const int32_t* base, const float* coef, TO* out, size_t rows, int Tin,
-                               int Tout, int nv, void* stream) {
-    EEGGAN_REQUIRE(x && base && coef && out, "resample_quads: null pointer");
+                               int Tout, int nv, void* stream, int fa = 0, int fc = 0, int fd = 0) {
+    EEGGAN_REQUIRE(x && coef && out, "resample_quads: null pointer");
+    EEGGAN_REQUIRE(base || (fd > 0 && fa >= 0 && (long long)fa * (Tout / 4) + (fc < 0 ? -(long long)fc : fc) < (1ll << 31)),
+                   "resample_quads: no table and no usable closed form (A=%d C=%d D=%d)", fa, fc, fd);
     EEGGAN_REQUIRE(rows > 0 && Tin > 0 && Tout > 0, "resample_quads: non-positive dimension");
     EEGGAN_REQUIRE(nv >= 1 && nv <= 4, "resample_quads: nv %d outside [1, 4]", nv);
     EEGGAN_REQUIRE(Tin % 4 == 0 && Tout % 4 == 0 && Tin >= 4 * nv,
@@ -398,7 +410,7 @@ static int resample_quads_impl(const TI* x, const int32_t* base, const float* co
     hipStream_t st = as_stream(stream);
     const bool nts = streams_past_caches(rows * ((size_t)Tin * sizeof(TI) + (size_t)Tout * sizeof(TO)));
 #define RQ(NV_, NTS_) \
-    hipLaunchKernelGGL((resample_quad_kernel<NV_, TI, TO, NTS_>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout)
+    hipLaunchKernelGGL((resample_quad_kernel<NV_, TI, TO, NTS_>), grid, dim3(256), 0, st, x, base, coef, out, (long long)rows, Tin, Tout, fa, fc, fd)
 #define RQN(NV_)                 \
     do {                         \
         if (nts) RQ(NV_, true);  \
@@ -418,6 +430,19 @@ static int resample_quads_impl(const TI* x, const int32_t* base, const float* co
 extern "C" int eeggan_resample_quads_t(const void* x, const int32_t* base, const float* coef, void* out, size_t rows,
                                        int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream) {
     auto run = [&](auto* xp, auto* op) { return resample_quads_impl(xp, base, coef, op, rows, Tin, Tout, nv, stream); };
+    if (in_bf16)
+        return out_bf16 ? run(static_cast<const __bf16*>(x), static_cast<__bf16*>(out))
+                        : run(static_cast<const __bf16*>(x), static_cast<float*>(out));
+    return out_bf16 ? run(static_cast<const float*>(x), static_cast<__bf16*>(out))
+                    : run(static_cast<const float*>(x), static_cast<float*>(out));
+}
+
+extern "C" int eeggan_resample_quads_affine_t(const void* x, int A, int C, int D, const float* coef, void* out, size_t rows,
+                                              int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream) {
+    EEGGAN_REQUIRE(D > 0 && A >= 0, "resample_quads_affine: closed form with A=%d D=%d", A, D);
+    auto run = [&](auto* xp, auto* op) {
+        return resample_quads_impl(xp, (const int32_t*)nullptr, coef, op, rows, Tin, Tout, nv, stream, A, C, D);
+    };
     if (in_bf16)
         return out_bf16 ? run(static_cast<const __bf16*>(x), static_cast<__bf16*>(out))
                         : run(static_cast<const __bf16*>(x), static_cast<float*>(out));

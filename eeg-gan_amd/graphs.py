@@ -11,6 +11,7 @@ hipGraph and replayed with fresh inputs copied into static buffers.
 from __future__ import annotations
 
 import contextlib
+import functools
 import gc
 import inspect
 import os
@@ -266,6 +267,17 @@ def _accepts(fn, name: str) -> bool:
     return name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
 
 
+def _names(fn, name: str) -> bool:
+    """Whether the callable has a parameter called ``name`` that its caller has not bound already (a
+    ``functools.partial`` with that keyword, or a wrapper that only forwards ``**kwargs``, decides it itself)."""
+    if isinstance(fn, functools.partial) and name in (fn.keywords or {}):
+        return False
+    try:
+        return name in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class GraphedTrainer(Trainer):
     """``Trainer`` whose discriminator and generator iterations replay captured HIP graphs.
 
@@ -298,6 +310,7 @@ class GraphedTrainer(Trainer):
         self._fakes_call: Optional[GraphedCall] = None
         self._zall: Optional[torch.Tensor] = None
         self._fake: Optional[torch.Tensor] = None
+        self._mix: Optional[torch.Tensor] = None
 
     def _capture(self, real, z, key):
         if layers.get_drop_mode() != "device":
@@ -338,6 +351,14 @@ class GraphedTrainer(Trainer):
             self._fake = self._pair[n:]
             self._fake.copy_(self._fakes_call.out[:n])
             d_loss_fn = lambda dis, gen, r, zz, **kw: self.d_loss(dis, gen, r, zz, fake=self._fake, **kw)  # noqa: E731
+        # The interpolation factors of the penalty come from a static buffer that train() fills from ONE draw per
+        # step.  Drawn inside the captured iteration (the loss's own uniform_()) they cost a launch in the penalty
+        # chain plus two fills of the generator's seed and offset cells on the launch stream before every replay.
+        self._mix = None
+        if _names(self.d_loss, "mixing"):
+            self._mix = torch.empty((n, 1, 1), device=real.device, dtype=torch.float32).uniform_()
+            with_fakes = d_loss_fn
+            d_loss_fn = lambda dis, gen, r, zz, **kw: with_fakes(dis, gen, r, zz, mixing=self._mix, **kw)  # noqa: E731
 
         def iteration(loss_fn, module, optimizer):
             """(graph of forward + backward [+ bucket pack], bucket, graph of the optimizer step)."""
@@ -437,16 +458,20 @@ class GraphedTrainer(Trainer):
             fakes = self._fakes_call()
         d_loss = None
         n = real.size(0)
+        mixes = None
+        if self._mix is not None:
+            mixes = torch.rand((repeats,) + tuple(self._mix.shape), device=self._mix.device, dtype=torch.float32)
         for i in range(repeats):
             if i > 0:
                 real = cudize(next(self.dataiter))["x"]
                 if real.shape != self._real.shape:
                     raise RuntimeError("GraphedTrainer: the batch shape changed inside a step")
             self._count_reals(n)
-            if fakes is not None:  # (the iteration's latents went into the fakes already); both inputs in one launch
-                self._stage([self._real, self._fake], [real, fakes[i * n:(i + 1) * n]])
+            extra = ([self._mix], [mixes[i]]) if mixes is not None else ([], [])
+            if fakes is not None:  # (the iteration's latents went into the fakes already); all inputs in one launch
+                self._stage([self._real, self._fake] + extra[0], [real, fakes[i * n:(i + 1) * n]] + extra[1])
             else:
-                self._stage([self._real, self._z], [real, zs[i]])
+                self._stage([self._real, self._z] + extra[0], [real, zs[i]] + extra[1])
             d_loss = self._replay(self._d_parts)
         self._stage([self._z], [zs[repeats]])
         g_loss = self._replay(self._g_parts)

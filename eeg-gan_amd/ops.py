@@ -1310,6 +1310,7 @@ def pixel_norm(h):
 
 # --------------------------------------------------------------------------------------- linear helpers
 USE_RESAMPLE_QUADS = os.environ.get("EEGGAN_RESAMPLE_QUADS", "1") != "0"  # (comparison switch)
+USE_RESAMPLE_AFFINE = os.environ.get("EEGGAN_RESAMPLE_AFFINE", "1") != "0"  # (comparison switch)
 
 
 def _gather_raw(x, table, out=None):
@@ -1325,9 +1326,13 @@ def _gather_raw(x, table, out=None):
     elif tuple(out.shape) != tuple(x.shape[:-1]) + (t_out,) or not out.is_contiguous():
         raise RuntimeError("resample: out does not match the result shape")
     if quads is not None and USE_RESAMPLE_QUADS and (x.data_ptr() | out.data_ptr()) % 16 == 0:
-        qbase, qcoef, nv = quads  # 16-byte accesses, four outputs per thread
-        call("eeggan_resample_quads_t", x.data_ptr(), qbase.data_ptr(), qcoef.data_ptr(), out.data_ptr(), rows, t_in,
-             t_out, nv, _bf(x), _bf(out), _stream())
+        qbase, qcoef, nv, affine = quads  # 16-byte accesses, four outputs per thread
+        if affine is not None and USE_RESAMPLE_AFFINE:  # the quad starts in closed form: no look-up before the loads
+            call("eeggan_resample_quads_affine_t", x.data_ptr(), affine[0], affine[1], affine[2], qcoef.data_ptr(),
+                 out.data_ptr(), rows, t_in, t_out, nv, _bf(x), _bf(out), _stream())
+        else:
+            call("eeggan_resample_quads_t", x.data_ptr(), qbase.data_ptr(), qcoef.data_ptr(), out.data_ptr(), rows, t_in,
+                 t_out, nv, _bf(x), _bf(out), _stream())
     else:
         call("eeggan_resample_t", x.data_ptr(), idx.data_ptr(), coef.data_ptr(), out.data_ptr(), rows, t_in, t_out,
              taps, _bf(x), _bf(out), _stream())

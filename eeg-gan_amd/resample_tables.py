@@ -108,6 +108,42 @@ def interleave_quads(coef: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(padded.reshape(groups, QUAD_LANES, 4, nv, 4).transpose(0, 2, 3, 1, 4)).reshape(-1)
 
 
+def affine_base(base: np.ndarray, t_in: int, nv: int):
+    """(A, C, D) with ``base[q] == min(max(A q + C, 0) // D // 4 * 4, t_in - 4 nv)`` for every quad, or None.
+
+    The first tap of a quad advances by the resampling ratio, so its 16-byte aligned start is an integer-affine
+    function of the quad index, clamped at both ends of the row.  With the closed form the kernel needs no table
+    look-up before it can issue its loads (``eeggan_resample_quads_affine_t``); a table the form does not reproduce
+    exactly keeps the look-up."""
+    from math import gcd
+    nq = len(base)
+    lim = t_in - 4 * nv
+    if lim <= 0 or nq == 0:
+        return (0, 0, 1) if (base == 0).all() else None
+    g = gcd(4 * t_in, 4 * nq)
+    q = np.arange(nq, dtype=np.int64)
+    b = base.astype(np.int64)
+    for k in (1, 2, 4, 8):
+        A, D = 4 * t_in // g * k, 4 * nq // g * k
+        lo, hi = -(1 << 40), 1 << 40
+        inner = (b > 0) & (b < lim)
+        if inner.any():
+            lo = max(lo, int((b[inner] * D - A * q[inner]).max()))
+            hi = min(hi, int(((b[inner] + 4) * D - 1 - A * q[inner]).min()))
+        left, right = b == 0, b == lim
+        if left.any():
+            hi = min(hi, int((4 * D - 1 - A * q[left]).min()))
+        if right.any():
+            lo = max(lo, int((lim * D - A * q[right]).max()))
+        if lo > hi:
+            continue
+        C = lo if hi >= 1 << 40 else (hi if lo <= -(1 << 40) else (lo + hi) // 2)
+        got = np.minimum(np.maximum(A * q + C, 0) // D // 4 * 4, lim)
+        if np.array_equal(got, b) and abs(C) < 1 << 30 and A * nq + abs(C) < 1 << 31:
+            return int(A), int(C), int(D)
+    return None
+
+
 def build_tables(t_in: int, p: int, q: int):
     """(forward, transpose) tables as numpy arrays: each is (idx[int32], coef[float32], Tin, Tout, taps,
     quads) with quads = (base[int32], coef[float32], nv) or None."""
@@ -128,7 +164,8 @@ _cache: Dict[Tuple, Tuple] = {}
 
 def device_tables(t_in: int, p: int, q: int, device: torch.device):
     """Device-resident tables, built and uploaded once per (length, ratio, device); the quad coefficients in the
-    kernel's lane-interleaved order (``interleave_quads``)."""
+    kernel's lane-interleaved order (``interleave_quads``), followed by the closed form of the quad starts
+    (``affine_base``) or None."""
     fr = Fraction(p, q)
     key = (t_in, fr.numerator, fr.denominator, str(device))
     hit = _cache.get(key)
@@ -136,7 +173,8 @@ def device_tables(t_in: int, p: int, q: int, device: torch.device):
         f, b = build_tables(t_in, fr.numerator, fr.denominator)
         dv = lambda a: torch.from_numpy(a).to(device)
         up = lambda t: (dv(t[0]), dv(t[1]), t[2], t[3], t[4],
-                        None if t[5] is None else (dv(t[5][0]), dv(interleave_quads(t[5][1])), t[5][2]))
+                        None if t[5] is None else (dv(t[5][0]), dv(interleave_quads(t[5][1])), t[5][2],
+                                                   affine_base(t[5][0], t[2], t[5][2])))
         hit = (up(f), up(b))
         _cache[key] = hit
     return hit

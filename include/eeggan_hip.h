@@ -504,6 +504,11 @@ int eeggan_resample_t(const void* x, const int32_t* idx, const float* coef, void
                       size_t rows, int Tin, int Tout, int taps, int in_bf16, int out_bf16, void* stream);
 int eeggan_resample_quads_t(const void* x, const int32_t* base, const float* coef, void* out,
                             size_t rows, int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream);
+/* eeggan_resample_quads_t without the table of quad starts: base[q] = min(max(A q + C, 0) / D / 4 * 4, Tin - 4 nv)
+ * (integer division), for tables whose starts follow that form exactly (every ratio of this path does; the host
+ * checks it when it builds a table) -- the kernel then issues its loads without waiting for a look-up. */
+int eeggan_resample_quads_affine_t(const void* x, int A, int C, int D, const float* coef, void* out,
+                                   size_t rows, int Tin, int Tout, int nv, int in_bf16, int out_bf16, void* stream);
 int eeggan_lrelu_drop_bwd_t(const void* g, const void* y, const float* drop, void* out,
                             int B, int C, int T, float slope, int bf16, void* stream);
 int eeggan_pixelnorm_drop_fwd_t(const void* h, const float* drop, void* y, float* d,

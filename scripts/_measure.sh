@@ -25,5 +25,8 @@ for n in ("r03_bench_line", "r03_bench_alpha05", "r03_bench_depth0_B32", "r03_be
           r.get("in_step", {}).get("frac"), r.get("whole_step", {}).get("frac"), r.get("traffic_over_algorithmic"))
 PY
 timeout -k 10 400 python scripts/kernel_roofline.py 32 64 512 > gpurun_out/r03_kernel_roofline_B32_B64_B512.txt 2>&1
+timeout -k 10 400 python scripts/bench_hbm.py 32 64 512 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_hbm_kernels_rotating_buffers.txt
+timeout -k 10 120 ./scripts/pn_probe 512 4 > gpurun_out/r03_probe_pixelnorm_B512.txt 2>&1
+( timeout -k 10 120 ./scripts/rs_probe 512 1280 1920 && timeout -k 10 120 ./scripts/rs_probe 512 1920 1280 ) > gpurun_out/r03_probe_resampler_B512.txt 2>&1
 bash scripts/_depth_sweep.sh
 timeout -k 10 500 python scripts/bench_metrics.py > gpurun_out/r03_metrics_bench.json 2> gpurun_out/r03_metrics_bench.err || tail -3 gpurun_out/r03_metrics_bench.err

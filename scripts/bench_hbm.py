@@ -32,29 +32,6 @@ def run(B, nbuf):
     gs = [torch.randn(B, C, T, device=dev) for _ in range(nbuf)]
     tag = f"B={B} x{nbuf}"
     y, d = ops.pixelnorm_drop_fwd_raw(hs[0], r)
-    outs = [torch.empty_like(h) for h in hs]
-    row(f"{tag} copy (ATen), calibration", timeit(rotating(lambda h, o: o.copy_(h), list(zip(hs, outs))), n),
-        nbytes=2.0 * 4 * B * C * T)
-    from eeggan_amd._lib import call
-    ds = [torch.empty(B, T, device=dev) for _ in hs]
-    st = torch.cuda.current_stream
-    row(f"{tag} pixelnorm fwd, outputs in turn too",
-        timeit(rotating(lambda h, o, dd: call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), r.data_ptr(), o.data_ptr(), dd.data_ptr(),
-                                              B, C, T, 1e-8, st().cuda_stream), list(zip(hs, outs, ds))), n),
-        nbytes=2.0 * 4 * B * C * T)
-    fn = rotating(lambda h, o, dd: call("eeggan_pixelnorm_drop_fwd", h.data_ptr(), r.data_ptr(), o.data_ptr(), dd.data_ptr(),
-                                        B, C, T, 1e-8, st().cuda_stream), list(zip(hs, outs, ds)))
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    e1.synchronize()
-    row(f"{tag} pixelnorm fwd, eager launches", e0.elapsed_time(e1) * 1e-3 / n, nbytes=2.0 * 4 * B * C * T)
-    del outs, ds
     row(f"{tag} pixelnorm fwd", timeit(rotating(lambda h: ops.pixelnorm_drop_fwd_raw(h, r), [(h,) for h in hs]), n),
         nbytes=2.0 * 4 * B * C * T)
     row(f"{tag} pixelnorm bwd", timeit(rotating(lambda g, h: ops.pixelnorm_drop_bwd_raw(g, h, r, d, 0.2), list(zip(gs, hs))), n),

@@ -132,6 +132,72 @@ __global__ __launch_bounds__(256) void quad_pipe_kernel(const float* __restrict_
     }
 }
 
+// A wave loads every input vector of its span ONCE (lanes along the row, 1 KB per instruction, no overlap between lanes)
+// into LDS and the lanes then pick their NV vectors from there.  A wave owns 64 consecutive quads of one row group.
+template <int NV, int ROWS, int NLOAD, bool NT>
+__global__ __launch_bounds__(256) void quad_wave_kernel(const float* __restrict__ x, const int* __restrict__ base,
+                                                        const float* __restrict__ coef, float* __restrict__ out,
+                                                        long long rows, int Tin, int Tout) {
+    __shared__ f32x4 stage[4][ROWS][NLOAD * 64];
+    const int NQ = Tout / 4, WPR = (NQ + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w = (long long)blockIdx.x * 4 + wave;
+    const long long rg = w / WPR;
+    const int wq = (int)(w - rg * WPR);
+    const int q = wq * 64 + lane;
+    const bool active = q < NQ;
+    const long long r0 = rg * ROWS;
+    const bool live = r0 < rows;
+    const int bf = base[wq * 64];
+    const int b0 = active ? base[q] : bf;
+    f32x4 cf[4][NV];
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                cf[e][v] = *reinterpret_cast<const f32x4*>(coef + ((((long long)(q >> 6) * 4 + e) * NV + v) * 64 + (q & 63)) * 4);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const long long row = r0 + r < rows ? r0 + r : rows - 1;
+#pragma unroll
+            for (int l = 0; l < NLOAD; ++l) {
+                const int at = bf + 4 * (l * 64 + lane);
+                if (at + 4 <= Tin) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(x + row * Tin + at);
+                    stage[wave][r][l * 64 + lane] = NT ? __builtin_nontemporal_load(p) : *p;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!live || !active) return;
+    const int off = (b0 - bf) >> 2;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        f32x4 xv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) xv[v] = stage[wave][r][off + v];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += cf[e][v][i] * xv[v][i];
+            o[e] = s;
+        }
+        if (r0 + r < rows) {
+            f32x4* p = reinterpret_cast<f32x4*>(out + (r0 + r) * Tout + 4 * q);
+            if (NT)
+                __builtin_nontemporal_store(o, p);
+            else
+                *p = o;
+        }
+    }
+}
+
 // The input rows of a workgroup staged through LDS: every input byte is fetched from memory once, by 16-byte loads
 // that run along the rows; the taps are then read from LDS.  A workgroup owns RW rows x all quads of those rows in
 // pieces of QW quads; thread = (row, quad).
@@ -230,6 +296,13 @@ int main(int argc, char** argv) {
             if (b0 > Tin - 4 * NV) b0 = Tin - 4 * NV;
             hb[q] = b0;
         }
+        int span = 0;  // widest span of a wave's 64 quads, in 16-byte vectors
+        for (int q0 = 0; q0 < NQ; q0 += 64) {
+            const int last = q0 + 63 < NQ ? q0 + 63 : NQ - 1;
+            const int sv = (hb[last] + 4 * NV - hb[q0]) / 4;
+            span = sv > span ? sv : span;
+        }
+        printf("NV=%d: a wave's span is %d vectors\n", NV, span);
         std::vector<float> hc((size_t)((NQ + 63) / 64 * 64) * 16 * NV, 0.125f);
         int* base;
         float* coef;
@@ -267,7 +340,22 @@ int main(int argc, char** argv) {
                                       dim3(256), 0, 0, x, base, coef, o, rows, Tin, Tout, chunks);                    \
                }, reps));                                                                                             \
     }
+#define WAVEK(NV_, ROWS_, NLOAD_, NT_)                                                                                \
+    if (NV == NV_ && (span + 63) / 64 <= NLOAD_) {                                                                    \
+        const long long waves = (rows + ROWS_ - 1) / ROWS_ * ((NQ + 63) / 64);                                        \
+        report("wave-staged NV=" #NV_ " rows=" #ROWS_ " loads/row=" #NLOAD_ " nt=" #NT_, time_us([&] {               \
+                   const float* x = xs[turn % NBUF]; float* o = os[turn % NBUF]; ++turn;                              \
+                   hipLaunchKernelGGL((quad_wave_kernel<NV_, ROWS_, NLOAD_, NT_>), dim3((unsigned)((waves + 3) / 4)), \
+                                      dim3(256), 0, 0, x, base, coef, o, rows, Tin, Tout);                            \
+               }, reps));                                                                                             \
+    }
 #define QUADS(NV_)                 \
+    WAVEK(NV_, 8, 1, false)        \
+    WAVEK(NV_, 8, 1, true)         \
+    WAVEK(NV_, 4, 1, true)         \
+    WAVEK(NV_, 8, 2, false)        \
+    WAVEK(NV_, 8, 2, true)         \
+    WAVEK(NV_, 4, 2, true)         \
     QUADP(NV_, 8, false, 8, -1)    \
     QUADP(NV_, 8, true, 8, -1)     \
     QUADP(NV_, 4, true, 4, -1)     \

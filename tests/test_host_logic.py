@@ -149,6 +149,14 @@ def test_resample_tables_match_interpolate_then_pool():
                             at = ((((qq // 64) * 4 + e) * nv + v) * 64 + qq % 64) * 4
                             assert np.array_equal(flat[at:at + 4], dense[qq, e, 4 * v:4 * v + 4])
                 assert np.array_equal(np.sort(flat[flat != 0]), np.sort(dense[dense != 0]))  # nothing else is non-zero
+                # the quad starts in closed form (what the kernel evaluates instead of reading ``base``)
+                from eeggan_amd.resample_tables import affine_base
+                form = affine_base(base, s_in, nv)
+                assert form is not None
+                fa, fc, fd = form
+                qs = np.arange(nq, dtype=np.int64)
+                assert np.array_equal(np.minimum(np.maximum(fa * qs + fc, 0) // fd // 4 * 4, s_in - 4 * nv), base)
+                assert affine_base(base[::-1].copy(), s_in, nv) is None or nq < 3 or (base == base[0]).all()
             assert quads is not None or t_in < 8  # every forward resampler of the schedule has a quad form
             # the transposed table is the adjoint: <A x, g> == <x, A^T g>
             g = torch.randn_like(y)

@@ -542,7 +542,15 @@ def test_resample_quad_form_matches_sparse_form(dev):
                     ref = ops._gather_raw(x, table)
                 finally:
                     ops.USE_RESAMPLE_QUADS = True
-                assert rel(ops._gather_raw(x, table), ref.double()) < 5e-7, (t_in, p, q)
+                got = ops._gather_raw(x, table)
+                assert rel(got, ref.double()) < 5e-7, (t_in, p, q)
+                # quad starts from the closed form (the default) and from the table: the same loads, bit for bit
+                assert table[5][3] is not None
+                try:
+                    ops.USE_RESAMPLE_AFFINE = False
+                    assert torch.equal(ops._gather_raw(x, table), got), (t_in, p, q)
+                finally:
+                    ops.USE_RESAMPLE_AFFINE = True
                 used += 1
         T = T * up[i] // dn[i]
     assert used >= 24
