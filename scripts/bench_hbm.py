@@ -5,7 +5,6 @@ the launch before it read the same bytes (NBUF = 1 is the loop over one tensor o
 
 usage: python scripts/bench_hbm.py [B ...] [--nbuf N]
 """
-import itertools
 import os
 import sys
 
@@ -13,15 +12,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eeggan_amd import ops, utils  # noqa: E402
-from kernel_roofline import timeit, row  # noqa: E402
+from kernel_roofline import rotating, timeit, row  # noqa: E402
 
 dev = torch.device("cuda", 0)
-
-
-def rotating(fn, sets):
-    """fn(*sets[i]) with i advancing on every call."""
-    turn = itertools.cycle(range(len(sets)))
-    return lambda: fn(*sets[next(turn)])
 
 
 def run(B, nbuf):

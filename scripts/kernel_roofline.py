@@ -5,6 +5,7 @@ algorithmic figure: 2*B*Cout*Cin*K*T flop, or the bytes of the logical tensors r
 
 usage: python scripts/kernel_roofline.py [B ...]      (default: 32 512)
 """
+import itertools
 import os
 import sys
 
@@ -36,6 +37,15 @@ def timeit(fn, n):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) * 1e-3 / n
+
+
+def rotating(fn, sets):
+    """fn(*sets[i]) with i advancing on every call: the launches of a timed loop take their inputs in turn, so that
+    none finds its input in a cache because the launch before it read the same bytes (with streaming stores a
+    250 MB input otherwise stays in the 256 MB memory-side cache from launch to launch: 0.83 instead of 0.66 of the
+    HBM peak for the resampler at 512 samples)."""
+    turn = itertools.cycle(range(len(sets)))
+    return lambda: fn(*sets[next(turn)])
 
 
 def row(name, t, flop=None, nbytes=None):
@@ -91,21 +101,31 @@ def run(B):
         row(f"conv 1x1 {cin}->{cout} T={T}", timeit(lambda: ops.conv1d_raw(x, w, b, None, in_scale=0.1, act=1, act_param=0.2), n),
             nbytes=4.0 * B * T * (cin + cout))
         del x
-    C, T = 64, 1920
-    h = torch.randn(B, C, T, device=dev)
-    g = torch.randn(B, C, T, device=dev)
+    # bandwidth-bound kernels: four sets of inputs taken in turn (see rotating)
+    C, T, NSET = 64, 1920, 4
+    hs = [torch.randn(B, C, T, device=dev) for _ in range(NSET)]
+    gs = [torch.randn(B, C, T, device=dev) for _ in range(NSET)]
     r = torch.rand(B, C, device=dev) + 0.5
+    h = hs[0]
     y, d = ops.pixelnorm_drop_fwd_raw(h, r)
-    row("pixelnorm+gdrop fwd [B,64,1920]", timeit(lambda: ops.pixelnorm_drop_fwd_raw(h, r), n), nbytes=2.0 * 4 * B * C * T)
-    row("pixelnorm+gdrop+lrelu bwd [B,64,1920]", timeit(lambda: ops.pixelnorm_drop_bwd_raw(g, y, r, d, 0.2), n), nbytes=3.0 * 4 * B * C * T)
-    row("lrelu+gdrop bwd [B,64,1920]", timeit(lambda: ops.lrelu_drop_bwd_raw(g, h, r, 0.2), n), nbytes=3.0 * 4 * B * C * T)
-    row("axpby (blend) [B,64,1920]", timeit(lambda: ops.axpby_raw(h, 0.3, g, 0.7), n), nbytes=3.0 * 4 * B * C * T)
+    pairs = list(zip(gs, hs))
+    row("pixelnorm+gdrop fwd [B,64,1920]", timeit(rotating(lambda a: ops.pixelnorm_drop_fwd_raw(a, r), [(a,) for a in hs]), n),
+        nbytes=2.0 * 4 * B * C * T)
+    row("pixelnorm+gdrop+lrelu bwd [B,64,1920]", timeit(rotating(lambda g, a: ops.pixelnorm_drop_bwd_raw(g, a, r, d, 0.2), pairs), n),
+        nbytes=3.0 * 4 * B * C * T)
+    row("lrelu+gdrop bwd [B,64,1920]", timeit(rotating(lambda g, a: ops.lrelu_drop_bwd_raw(g, a, r, 0.2), pairs), n),
+        nbytes=3.0 * 4 * B * C * T)
+    row("axpby (blend) [B,64,1920]", timeit(rotating(lambda g, a: ops.axpby_raw(a, 0.3, g, 0.7), pairs), n),
+        nbytes=3.0 * 4 * B * C * T)
+    del gs, pairs
     with torch.no_grad():
-        hc = h[:, :, :1280].contiguous()
-        row("resample 1280->1920 (x3/2) [B,64,.]", timeit(lambda: utils.resample_signal(hc, 1280, 1920), n),
+        hcs = [(a[:, :, :1280].contiguous(),) for a in hs]
+        row("resample 1280->1920 (x3/2) [B,64,.]", timeit(rotating(lambda a: utils.resample_signal(a, 1280, 1920), hcs), n),
             nbytes=4.0 * B * C * (1280 + 1920))
-        row("resample 1920->1280 (x2/3) [B,64,.]", timeit(lambda: utils.resample_signal(h, 1920, 1280), n),
+        del hcs
+        row("resample 1920->1280 (x2/3) [B,64,.]", timeit(rotating(lambda a: utils.resample_signal(a, 1920, 1280), [(a,) for a in hs]), n),
             nbytes=4.0 * B * C * (1280 + 1920))
+        del hs
         xm = torch.randn(B, 256, 32, device=dev)
         row("minibatch stddev fwd [B,256,32]", timeit(lambda: ops.minibatch_stddev(xm, 4), n), nbytes=4.0 * B * 32 * (256 + 257))
     real = torch.randn(B, 5, T, device=dev)
