@@ -176,6 +176,33 @@ def test_elementwise_forms(dev, bf16_storage):
     assert torch.equal(ops.cast_raw(f.bfloat16().to(dev), torch.float32).cpu(), f.bfloat16().float())
 
 
+def test_elementwise_forms_beyond_the_caches(dev, bf16_storage):
+    """The streaming (non-temporal) forms, taken from 192 MB of tensors on: the same arithmetic, so the results equal
+    those of the cached forms on the same values bit for bit (checked on the first rows, which a small launch of the
+    cached form recomputes) and the float64 reference to bfloat16 rounding."""
+    from eeggan_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    B, C, T = 512, 64, 1920  # 126 MB per bfloat16 tensor
+    a, b = (torch.randn(B, C, T, generator=gen).bfloat16() for _ in range(2))
+    r = torch.rand(B, C, generator=gen) + 0.5
+    ad, bd, rd = a.to(dev), b.to(dev), r.to(dev)
+    head = slice(0, 4)
+    out = ops.lrelu_drop_bwd_raw(ad, bd, rd, 0.2)
+    assert torch.equal(out[head], ops.lrelu_drop_bwd_raw(ad[head].contiguous(), bd[head].contiguous(), rd[head].contiguous(), 0.2))
+    ref = a[-2:].double() * r[-2:].double()[:, :, None] * torch.where(b[-2:].double() > 0, 1.0, 0.2)
+    assert rel(out[-2:], ref) < ROUND
+    out = ops.axpby_raw(ad, 0.3, bd, 0.7)
+    assert torch.equal(out[head], ops.axpby_raw(ad[head].contiguous(), 0.3, bd[head].contiguous(), 0.7))
+    assert rel(out[-2:], 0.3 * a[-2:].double() + 0.7 * b[-2:].double()) < ROUND
+    # (the channel norm sums in another order at another batch size: its small launch agrees to rounding)
+    y, d = ops.pixelnorm_drop_fwd_raw(ad, rd)
+    y4, d4 = ops.pixelnorm_drop_fwd_raw(ad[head].contiguous(), rd[head].contiguous())
+    assert rel(y[head], y4.double()) < ROUND and rel(d[head], d4.double()) < 1e-6
+    g = ops.pixelnorm_drop_bwd_raw(bd, y, rd, d, 0.2)
+    g4 = ops.pixelnorm_drop_bwd_raw(bd[head].contiguous(), y[head].contiguous(), rd[head].contiguous(), d[head].contiguous(), 0.2)
+    assert rel(g[head], g4.double()) < ROUND
+
+
 def test_unsupported_combinations_fail_loudly(dev, bf16_storage):
     from eeggan_amd import ops
     from eeggan_amd._lib import EegganError

@@ -556,6 +556,23 @@ def test_resample_quad_form_matches_sparse_form(dev):
     assert used >= 24
 
 
+def test_resample_beyond_the_caches(dev):
+    """From 192 MB of input + output on, the quad kernel stores with the streaming hint: the first rows equal a
+    small launch's bit for bit, the last ones the sparse-tap kernel's to the last bit or two."""
+    ops = _ops()
+    from eeggan_amd.resample_tables import device_tables
+    fwd, _ = device_tables(1280, 3, 2, dev)
+    x = torch.randn(280, 64, 1280, device=dev)  # 92 MB in, 138 MB out
+    y = ops._gather_raw(x, fwd)
+    assert torch.equal(y[:3], ops._gather_raw(x[:3].contiguous(), fwd))
+    try:
+        ops.USE_RESAMPLE_QUADS = False
+        ref = ops._gather_raw(x[-3:].contiguous(), fwd)
+    finally:
+        ops.USE_RESAMPLE_QUADS = True
+    assert rel(y[-3:], ref.double()) < 5e-7
+
+
 @pytest.mark.parametrize("B", [4, 8, 32, 2])
 def test_minibatch_stddev_orders(dev, B):
     ops = _ops()
