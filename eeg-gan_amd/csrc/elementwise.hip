@@ -367,12 +367,24 @@ __global__ __launch_bounds__(256) void axpby_kernel(const ET* __restrict__ a, fl
     }
 }
 
+// (VEC: 16-byte items; a sample's length is then a multiple of 4, so an item never straddles two samples)
+template <bool VEC>
 __global__ __launch_bounds__(256) void mix_batch_kernel(const float* __restrict__ real, const float* __restrict__ fake,
                                                         const float* __restrict__ mix, float* __restrict__ out,
                                                         size_t n, size_t per) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float m = mix[i / per];
-        out[i] = m * real[i] + (1.f - m) * fake[i];
+    constexpr int W = VEC ? 4 : 1;
+    const size_t items = n / W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (size_t)gridDim.x * 256) {
+        const float m = mix[i * W / per];
+        if (VEC) {
+            const f32x4 a = ld4(real + 4 * i), b = ld4(fake + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = m * a[k] + (1.f - m) * b[k];
+            st4(out + 4 * i, o);
+        } else {
+            out[i] = m * real[i] + (1.f - m) * fake[i];
+        }
     }
 }
 
@@ -752,8 +764,12 @@ extern "C" int eeggan_mix_batch(const float* real, const float* fake, const floa
                                 void* stream) {
     EEGGAN_REQUIRE(real && fake && mix && out && B > 0 && per > 0, "mix_batch: null pointer or empty");
     const size_t n = (size_t)B * per;
-    hipLaunchKernelGGL(mix_batch_kernel, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), real, fake, mix, out, n,
-                       per);
+    if (per % 4 == 0 && aligned16(real) && aligned16(fake) && aligned16(out))
+        hipLaunchKernelGGL(mix_batch_kernel<true>, dim3(blocks_stream(n / 4)), dim3(256), 0, as_stream(stream), real, fake,
+                           mix, out, n, per);
+    else
+        hipLaunchKernelGGL(mix_batch_kernel<false>, dim3(blocks_for(n)), dim3(256), 0, as_stream(stream), real, fake, mix,
+                           out, n, per);
     return check_launch("mix_batch");
 }
 
