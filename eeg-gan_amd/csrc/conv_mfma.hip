@@ -852,6 +852,16 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                         const float bb = has_bias ? pre_b[i] : 0.f;
                         const float dd = has_drop ? pre_d[i][n] : 1.f;
                         const long long row = ((long long)bc * a.Cout + cc) * a.T;
+                        // the mask values of the block's four stores, fetched before the first of them: a load
+                        // between two stores makes the second wait for the first (one counter for both)
+                        f32x4 mk[4];
+                        if (ACT == EEGGAN_ACT_MASK && VEC) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int t = t0 + 8 * q;
+                                mk[q] = ld4(reinterpret_cast<const AT*>(a.act_aux) + row + ((cok && t < a.T) ? t : 0));
+                            }
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int t = t0 + 8 * q;
@@ -870,7 +880,7 @@ __global__ __launch_bounds__(NTHR) void conv_fwd_kernel(ConvArgs a) {
                             }
                             if (ACT == EEGGAN_ACT_MASK) {
                                 if (VEC) {
-                                    const f32x4 m = ld4(reinterpret_cast<const AT*>(a.act_aux) + o);
+                                    const f32x4 m = mk[q];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : v[e] * a.act_param;
                                 } else {
@@ -2094,10 +2104,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReducePack pk) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a4[e] += (double)v[u][e];
             }
-            for (; s < nsplit; s += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long long)s * E + i);
+            if (s < nsplit) {
+                // the last (in a grouped launch: the only) up to seven slabs of the wave, all in flight at once: one
+                // load per iteration made this a chain of dependent round trips (the grouped weight gradient leaves
+                // ~16 slabs per layer, i.e. four per wave, and none for the loop above).  Same order of additions.
+                f32x4 v[7];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a4[e] += (double)v[e];
+                for (int u = 0; u < 7; ++u) {
+                    const int su = s + 4 * u < nsplit ? s + 4 * u : s;
+                    v[u] = *reinterpret_cast<const f32x4*>(ws + (long long)su * E + i);
+                }
+#pragma unroll
+                for (int u = 0; u < 7; ++u)
+                    if (s + 4 * u < nsplit) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a4[e] += (double)v[u][e];
+                    }
             }
         }
 #pragma unroll

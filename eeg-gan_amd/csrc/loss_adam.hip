@@ -239,36 +239,56 @@ __global__ __launch_bounds__(256) void adam_kernel(Pack pk, float lr, float b1, 
     int64_t start;
     if (!locate(pk, blockIdx.x, &ti, &start)) return;
     const eeggan_adam_tensor t = pk.t[ti];
-    const float step = t.step[0] + 1.f;
-    const float bc1 = 1.f - powf(b1, step);
-    const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, step));
-    const float lr_c = lr / bc1;
     int64_t end = start + CHUNK;
     if (end > t.n) end = t.n;
     const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) |
                        reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
     int64_t i0 = start;
-    if (vec) {  // 16-byte accesses over the whole-float4 part of the chunk (start is a multiple of 4)
+    if (vec && end - start >= 4) {  // 16-byte accesses over the whole-float4 part of the chunk (start is a multiple of 4)
+        // A chunk is four 16-byte items per thread: all sixteen loads go out before the first result is stored (a
+        // loop of load, compute, store made four dependent round trips of it, each waiting for the stores of the one
+        // before), and before the step counter is looked at.
         const int64_t nv = (end - start) / 4;
-        for (int64_t k = threadIdx.x; k < nv; k += 256) {
-            const int64_t i = start + 4 * k;
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(t.g + i);
-            f32x4 m4 = *reinterpret_cast<const f32x4*>(t.m + i);
-            f32x4 v4 = *reinterpret_cast<const f32x4*>(t.v + i);
-            f32x4 p4 = *reinterpret_cast<const f32x4*>(t.p + i);
+        constexpr int U = (int)(CHUNK / 4 / 256);
+        f32x4 g4[U], m4[U], v4[U], p4[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float g = g4[e] * grad_scale;
-                m4[e] = b1 * m4[e] + (1.f - b1) * g;
-                v4[e] = b2 * v4[e] + (1.f - b2) * g * g;
-                p4[e] -= lr_c * m4[e] / (sqrtf(v4[e]) * inv_sqrt_bc2 + eps);
+        for (int u = 0; u < U; ++u) {
+            // (items past the chunk's end read item 0 again, which exists: no branch between the loads)
+            const int64_t k = threadIdx.x + 256 * u;
+            const int64_t i = start + 4 * (k < nv ? k : 0);
+            g4[u] = *reinterpret_cast<const f32x4*>(t.g + i);
+            m4[u] = *reinterpret_cast<const f32x4*>(t.m + i);
+            v4[u] = *reinterpret_cast<const f32x4*>(t.v + i);
+            p4[u] = *reinterpret_cast<const f32x4*>(t.p + i);
+        }
+        const float step_v = t.step[0] + 1.f;
+        const float bc1_v = 1.f - powf(b1, step_v);
+        const float isb2_v = rsqrtf(1.f - powf(b2, step_v));
+        const float lr_v = lr / bc1_v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = threadIdx.x + 256 * u;
+            if (k < nv) {
+                const int64_t i = start + 4 * k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = g4[u][e] * grad_scale;
+                    m4[u][e] = b1 * m4[u][e] + (1.f - b1) * g;
+                    v4[u][e] = b2 * v4[u][e] + (1.f - b2) * g * g;
+                    p4[u][e] -= lr_v * m4[u][e] / (sqrtf(v4[u][e]) * isb2_v + eps);
+                }
+                *reinterpret_cast<f32x4*>(t.m + i) = m4[u];
+                *reinterpret_cast<f32x4*>(t.v + i) = v4[u];
+                *reinterpret_cast<f32x4*>(t.p + i) = p4[u];
             }
-            *reinterpret_cast<f32x4*>(t.m + i) = m4;
-            *reinterpret_cast<f32x4*>(t.v + i) = v4;
-            *reinterpret_cast<f32x4*>(t.p + i) = p4;
         }
         i0 = start + 4 * nv;
+        if (i0 >= end) return;
     }
+    const float step = t.step[0] + 1.f;
+    const float bc1 = 1.f - powf(b1, step);
+    const float inv_sqrt_bc2 = rsqrtf(1.f - powf(b2, step));
+    const float lr_c = lr / bc1;
     for (int64_t i = i0 + threadIdx.x; i < end; i += 256) {
         const float g = t.g[i] * grad_scale;
         const float m = b1 * t.m[i] + (1.f - b1) * g;
@@ -303,7 +323,32 @@ __global__ __launch_bounds__(256) void multi_axpby_kernel(Pack pk, float alpha, 
     const eeggan_adam_tensor t = pk.t[ti];
     int64_t end = start + CHUNK;
     if (end > t.n) end = t.n;
-    for (int64_t i = start + threadIdx.x; i < end; i += 256) t.p[i] = alpha * t.p[i] + beta * t.g[i];
+    int64_t i0 = start;
+    if (((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g)) & 15) == 0 && end - start >= 4) {
+        // (all loads of the chunk before its first store, like adam_kernel)
+        const int64_t nv = (end - start) / 4;
+        constexpr int U = (int)(CHUNK / 4 / 256);
+        f32x4 p4[U], g4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = threadIdx.x + 256 * u;
+            const int64_t i = start + 4 * (k < nv ? k : 0);
+            p4[u] = *reinterpret_cast<const f32x4*>(t.p + i);
+            g4[u] = *reinterpret_cast<const f32x4*>(t.g + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = threadIdx.x + 256 * u;
+            if (k < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = alpha * p4[u][e] + beta * g4[u][e];
+                *reinterpret_cast<f32x4*>(t.p + start + 4 * k) = o;
+            }
+        }
+        i0 = start + 4 * nv;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < end; i += 256) t.p[i] = alpha * t.p[i] + beta * t.g[i];
 }
 
 int make_pack(const char* what, const eeggan_adam_tensor* table, int first, int ntensors, Pack* pk, int64_t* blocks) {

@@ -676,7 +676,7 @@ def test_losses(dev):
 def test_adam_matches_torch(dev):
     from eeggan_amd.optim import Adam
     g = torch.Generator().manual_seed(9)
-    shapes = [(256, 256, 32), (64, 64, 3), (64,), (5, 64, 1), (1,)]
+    shapes = [(256, 256, 32), (64, 64, 3), (64,), (5, 64, 1), (1,), (7,), (4099,), (3, 1367)]  # (whole chunks, ragged ends, < 4)
     ps = [torch.randn(s, generator=g) for s in shapes]
     mine = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
     ref = [torch.nn.Parameter(p.clone().double()) for p in ps]
