@@ -28,5 +28,6 @@ timeout -k 10 400 python scripts/kernel_roofline.py 32 64 512 > gpurun_out/r03_k
 timeout -k 10 400 python scripts/bench_hbm.py 32 64 512 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_hbm_kernels_rotating_buffers.txt
 timeout -k 10 120 ./scripts/pn_probe 512 4 > gpurun_out/r03_probe_pixelnorm_B512.txt 2>&1
 ( timeout -k 10 120 ./scripts/rs_probe 512 1280 1920 && timeout -k 10 120 ./scripts/rs_probe 512 1920 1280 ) > gpurun_out/r03_probe_resampler_B512.txt 2>&1
+bash scripts/_pmc_hbm.sh > /dev/null
 bash scripts/_depth_sweep.sh
 timeout -k 10 500 python scripts/bench_metrics.py > gpurun_out/r03_metrics_bench.json 2> gpurun_out/r03_metrics_bench.err || tail -3 gpurun_out/r03_metrics_bench.err
