@@ -8,6 +8,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 #define CHECK(x)                                                                        \
     do {                                                                                \
@@ -21,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // PERIOD > 0: the coefficient blocks repeat with that period over the quads (a rational ratio's interior does), so the
 // table a launch touches is a few hundred bytes and stays in the vector cache
 // PERIOD < 0: the table laid out so that the 64 lanes of a wave read 1 KB in one piece: [q / 64][e][v][q % 64][4]
-template <int NV, int ROWS, bool NTS, int PERIOD = 0>
+template <int NV, int ROWS, bool NTS, int PERIOD = 0, bool UNAL = false>
 __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, const int* __restrict__ base,
                                                    const float* __restrict__ coef, float* __restrict__ out, long long rows,
                                                    int Tin, int Tout, int chunks) {
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(256) void quad_kernel(const float* __restrict__ x, 
         for (int r = 0; r < ROWS; ++r) {
             const long long row = r0 + r < rows ? r0 + r : rows - 1;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) xv[r][v] = *reinterpret_cast<const f32x4*>(x + row * Tin + b0 + 4 * v);
+            for (int v = 0; v < NV; ++v)
+                xv[r][v] = UNAL ? (f32x4)*reinterpret_cast<const f32x4u*>(x + row * Tin + b0 + 4 * v)
+                                : *reinterpret_cast<const f32x4*>(x + row * Tin + b0 + 4 * v);
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -287,12 +290,14 @@ int main(int argc, char** argv) {
         fflush(stdout);
     };
     printf("--- %d samples, %d -> %d\n", B, Tin, Tout);
+    const bool unal = argc > 5;  // bases at any sample (4-byte aligned 16-byte loads), as an unaligned table would have them
     const bool exact = argc > 4;  // taps start exactly at the quad's first input: with Tin == Tout and NV = 1 a row-strided copy
     for (int NV = exact ? 1 : 2; NV <= 3; ++NV) {
         std::vector<int> hb(NQ);
         for (int q = 0; q < NQ; ++q) {
             long long first = (long long)4 * q * Tin / Tout - (exact ? 0 : (NV == 3 ? 2 : 1));
-            int b0 = (int)(first < 0 ? 0 : first) & ~3;
+            int b0 = (int)(first < 0 ? 0 : first);
+            if (!unal) b0 &= ~3;
             if (b0 > Tin - 4 * NV) b0 = Tin - 4 * NV;
             hb[q] = b0;
         }
@@ -349,7 +354,19 @@ int main(int argc, char** argv) {
                                       dim3(256), 0, 0, x, base, coef, o, rows, Tin, Tout);                            \
                }, reps));                                                                                             \
     }
+#define QUADU(NV_, ROWS_, NTS_, PER)                                                                                  \
+    if (NV == NV_ && unal) {                                                                                          \
+        const int chunks = PER / ROWS_;                                                                               \
+        const long long threads = (rows + PER - 1) / PER * NQ;                                                        \
+        report("quad UNALIGNED NV=" #NV_ " rows/pass=" #ROWS_ " nts=" #NTS_ " rows/thread=" #PER, time_us([&] {       \
+                   const float* x = xs[turn % NBUF]; float* o = os[turn % NBUF]; ++turn;                              \
+                   hipLaunchKernelGGL((quad_kernel<NV_, ROWS_, NTS_, -1, true>), dim3((unsigned)((threads + 255) / 256)), \
+                                      dim3(256), 0, 0, x, base, coef, o, rows, Tin, Tout, chunks);                    \
+               }, reps));                                                                                             \
+    }
 #define QUADS(NV_)                 \
+    QUADU(NV_, 8, true, 8)         \
+    QUADU(NV_, 8, false, 8)        \
     WAVEK(NV_, 8, 1, false)        \
     WAVEK(NV_, 8, 1, true)         \
     WAVEK(NV_, 4, 1, true)         \
