@@ -26,6 +26,7 @@ for n in ("r03_bench_line", "r03_bench_alpha05", "r03_bench_depth0_B32", "r03_be
 PY
 timeout -k 10 400 python scripts/kernel_roofline.py 32 64 512 > gpurun_out/r03_kernel_roofline_B32_B64_B512.txt 2>&1
 timeout -k 10 400 python scripts/bench_hbm.py 32 64 512 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_hbm_kernels_rotating_buffers.txt
+timeout -k 10 300 python scripts/bench_hbm.py 512 --bf16 2>&1 | grep -v amdgpu.ids > gpurun_out/r03_hbm_kernels_rotating_buffers_bf16.txt
 timeout -k 10 120 ./scripts/pn_probe 512 4 > gpurun_out/r03_probe_pixelnorm_B512.txt 2>&1
 ( timeout -k 10 120 ./scripts/rs_probe 512 1280 1920 && timeout -k 10 120 ./scripts/rs_probe 512 1920 1280 ) > gpurun_out/r03_probe_resampler_B512.txt 2>&1
 bash scripts/_pmc_hbm.sh > /dev/null
